@@ -1,0 +1,164 @@
+/*
+ * lpr_engine.h -- C ABI of the MI355X (gfx950) simplex pivot engine.
+ *
+ * This is the drop-in boundary for the dense-tableau hot path of
+ * Storm-Tarran/LPR_381_Group_V22.  The reference has no FFI layer of its own;
+ * its de-facto boundary is the public surface of three C# classes consumed by
+ * Program.cs.  Every entry point below names the reference member it replaces
+ * (paths relative to LPR_381_Group_V22/ in the reference tree).  The C# side
+ * binds these with [DllImport("lpr_engine")] -- see INTEGRATION.md.
+ *
+ * Conventions
+ *   - extern "C", plain pointers + sizes, no exceptions cross this boundary.
+ *   - every function returns an lpr_status (>= 0: solver outcome, < 0: error);
+ *     the text of the last error on the calling thread is lpr_last_error().
+ *   - input buffers are borrowed for the duration of the call only (P/Invoke
+ *     pins blittable arrays); outputs go to caller-allocated buffers.
+ *   - handles are opaque, owned by the library, not thread-safe; one engine
+ *     == one HIP device + one stream.
+ *   - matrices are row-major fp64 (C# double[,] is contiguous row-major);
+ *     column / variable indices are 0-based; tableau row 0 is the Z row, so
+ *     constraint rows (and pivot-log rows of the tableau solver) are 1-based
+ *     exactly as in PrimalSimplexSolver.cs:138,142.
+ *   - all arithmetic on the device is IEEE binary64, no FMA contraction,
+ *     true division -- bit-for-bit the C# expressions it replaces.
+ */
+#ifndef LPR_ENGINE_H
+#define LPR_ENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LPR_ABI_VERSION 1
+
+/* Solver outcomes mirror the reference's behaviours one-to-one:
+ *   OPTIMAL              PrimalSimplexSolver.cs:110-126 / RevisedPrimalSimplexSolver.cs:124-146
+ *   UNBOUNDED            PrimalSimplexSolver.cs:129-135 (print + break) /
+ *                        RevisedPrimalSimplexSolver.cs:178-179 (throw "Unbounded problem ...")
+ *   INFEASIBLE_BASIS     RevisedPrimalSimplexSolver.cs:90-91
+ *   PIVOT_TOO_SMALL      RevisedPrimalSimplexSolver.cs:267
+ *   ENTERING_ALREADY_BASIC RevisedPrimalSimplexSolver.cs:182-183
+ *   PIVOT_LIMIT          (no reference equivalent: the C# loops are uncapped; returned only when
+ *                         the caller sets max_pivots)
+ *   BB_NODE_CAP          BranchBoundSimplexSolver.cs:1038-1042 ("Potential infinite loop detected")
+ */
+typedef enum lpr_status {
+    LPR_OK_OPTIMAL = 0,
+    LPR_UNBOUNDED = 1,
+    LPR_INFEASIBLE_BASIS = 2,
+    LPR_PIVOT_TOO_SMALL = 3,
+    LPR_ENTERING_ALREADY_BASIC = 4,
+    LPR_PIVOT_LIMIT = 5,
+    LPR_BB_NODE_CAP = 6,
+    LPR_BAD_ARGUMENT = -1,
+    LPR_DEVICE_ERROR = -2,
+    LPR_OUT_OF_MEMORY = -3
+} lpr_status;
+
+/* Constraint relation codes for lpr_tableau_from_lp (InputFileParser.Constraint.Relation,
+ * IO/InputFileParser.cs:70-82).  Anything that is not ">=" is treated as "<=" by the reference
+ * (PrimalSimplexSolver.cs:36-50). */
+enum { LPR_REL_LE = 0, LPR_REL_GE = 1, LPR_REL_EQ = 2 };
+
+typedef struct lpr_engine lpr_engine;
+typedef struct lpr_tableau lpr_tableau;
+
+/* ------------------------------------------------------------------ engine */
+
+int lpr_abi_version(void);
+/* Thread-local text of the last failure ("" if none). */
+const char* lpr_last_error(void);
+/* Binds HIP device `device`, creates the engine stream.  LPR_DEVICE_ERROR if no gfx950 device. */
+int lpr_engine_open(int device, lpr_engine** out);
+int lpr_engine_close(lpr_engine* e);
+/* Blocks until all work queued on the engine stream has finished. */
+int lpr_engine_sync(lpr_engine* e);
+/* The engine's hipStream_t as an integer (for callers that time with their own HIP events). */
+uint64_t lpr_engine_stream(lpr_engine* e);
+
+/* ------------------------------------------------------- tableau (primal) */
+
+/* Replaces `new PrimalSimplexSolver(objective, constraints, isMaximization)`
+ * (Simplex/PrimalSimplexSolver.cs:27-87), built on the device:
+ *   row 0      = -c (max) or +c (min)                         :61-62
+ *   ">=" rows  negated incl. RHS; "=" and others kept as "<=" :36-50
+ *   row i+1    = [first min(n, ncoef[i]) coeffs | e_i | rhs]  :68-82
+ *   basis[i]   = n + i                                         :78
+ * A is m x lda row-major (lda >= n); ncoef may be NULL (== n for every row). */
+int lpr_tableau_from_lp(lpr_engine* e, int n, int m, const double* objective,
+                        const double* A, int lda, const int32_t* ncoef,
+                        const int8_t* relation, const double* rhs, int is_max,
+                        lpr_tableau** out);
+
+/* Adopts a ready (rows x cols) row-major tableau + basis (rows-1 column indices); the entry used
+ * by BranchAndBoundAdapter-style callers that already hold a double[,] (BranchAndBoundAdapter.cs:31-46). */
+int lpr_tableau_create(lpr_engine* e, int rows, int cols, const double* rowmajor,
+                       const int32_t* basis, lpr_tableau** out);
+
+/* Benchmark input: dense random LP generated ON the device by the counter-based
+ * generator documented in DESIGN.md (SplitMix64 keyed by (seed, stream, i, j)), so that the
+ * 402.8 MB tableau of the m=4096,n=8192 configuration never crosses PCIe:
+ *   A[i][j] ~ U(0,1), b_i = 1 + U(0,1)*n/4, c_j ~ U(0,1), all "<=", maximise. */
+int lpr_tableau_synthetic(lpr_engine* e, int m, int n, uint64_t seed, lpr_tableau** out);
+
+int lpr_tableau_destroy(lpr_tableau* t);
+int lpr_tableau_shape(const lpr_tableau* t, int* rows, int* cols, int* ld);
+
+/* Solver options.  Zero-initialise, then set fields; defaults equal the reference's literals. */
+typedef struct lpr_solve_opts {
+    int64_t max_pivots;    /* <= 0: uncapped like PrimalSimplexSolver.cs:107 */
+    int32_t time_kernels;  /* != 0: launch eagerly and bracket every rank-1 update launch with HIP
+                              events on the engine stream; read back with lpr_tableau_kernel_stats */
+    int32_t batch;         /* pivots queued between host polls of the device status word (0: auto) */
+    int32_t variant;       /* rank-1 update kernel variant (0: auto); for tuning only, same bits */
+    int32_t reserved;
+} lpr_solve_opts;
+
+typedef struct lpr_solve_result {
+    int32_t status;        /* lpr_status */
+    int32_t reserved;
+    int64_t pivots;        /* pivots performed by THIS call */
+    int64_t total_pivots;  /* pivots performed on this tableau so far (== C# `iteration`) */
+    double z;              /* T[0, cols-1] at exit (FinalZ, PrimalSimplexSolver.cs:113); the C#
+                              leaves FinalZ = 0 on the unbounded exit -- the host mirror does that */
+} lpr_solve_result;
+
+/* Replaces PrimalSimplexSolver.Solve() (Simplex/PrimalSimplexSolver.cs:102-150): repeats
+ * FindEnteringVariable -> FindLeavingVariable -> Pivot -> basicVariables[r-1] = e on the device
+ * until optimal / unbounded / max_pivots.  No tableau data crosses the host boundary. */
+int lpr_primal_solve(lpr_tableau* t, const lpr_solve_opts* opts, lpr_solve_result* res);
+
+/* Single-step forms of the same three private methods, for callers (and tests) that drive the
+ * loop themselves:
+ *   lpr_select_entering  FindEnteringVariable  PrimalSimplexSolver.cs:152-167   (-1: optimal)
+ *   lpr_select_leaving   FindLeavingVariable   PrimalSimplexSolver.cs:169-191   (-1: unbounded)
+ *   lpr_pivot            Pivot                 PrimalSimplexSolver.cs:193-211   (+ basis update :142)
+ */
+int lpr_select_entering(lpr_tableau* t, int32_t* col);
+int lpr_select_leaving(lpr_tableau* t, int32_t col, int32_t* row);
+int lpr_pivot(lpr_tableau* t, int32_t row, int32_t col);
+
+/* Replaces ExtractSolution() + FinalZ (PrimalSimplexSolver.cs:213-252, :113): x has n entries. */
+int lpr_extract_solution(lpr_tableau* t, int n, double* x, double* z);
+
+/* Result accessors (PrimalSimplexSolver.cs:18-24, 269-278). */
+int lpr_tableau_read(lpr_tableau* t, double* rowmajor_out);            /* rows*cols doubles   */
+int lpr_tableau_read_block(lpr_tableau* t, int row0, int nrows, int col0, int ncols,
+                           double* out);                               /* nrows*ncols doubles */
+int lpr_basis_read(lpr_tableau* t, int32_t* basis_out);                /* rows-1 ints         */
+/* Pivot log: (row, col) pairs in order, row 1-based like the C# console line (:138).  Returns the
+ * number of pairs written through *count (at most cap). */
+int lpr_pivot_log_read(lpr_tableau* t, int32_t* rows_out, int32_t* cols_out, int64_t cap,
+                       int64_t* count);
+
+/* Timing of the rank-1 update launches recorded while opts.time_kernels was set:
+ * launches, summed and average duration in milliseconds (HIP events on the engine stream). */
+int lpr_tableau_kernel_stats(lpr_tableau* t, int64_t* launches, double* total_ms, double* avg_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LPR_ENGINE_H */

@@ -1,0 +1,14 @@
+"""MI355X-native simplex pivot engine behind the solver surface of LPR_381_Group_V22.
+
+Importing this package loads ``_lib/liblpr_engine.so`` (hand-written HIP for gfx950, built by
+``__graft_entry__.build()``); there is no CPU fallback.
+"""
+from . import _native
+from .engine import Engine, Tableau, default_engine
+from .input_file_parser import Constraint, InputFileParser
+from .primal_simplex_solver import PrimalSimplexSolver
+
+__all__ = [
+    "Engine", "Tableau", "default_engine", "Constraint", "InputFileParser",
+    "PrimalSimplexSolver", "_native",
+]

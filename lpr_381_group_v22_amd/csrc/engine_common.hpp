@@ -1,0 +1,88 @@
+// engine_common.hpp -- internal definitions shared by the gfx950 engine sources.
+// Not part of the ABI (include/lpr_engine.h is).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/lpr_engine.h"
+
+// The C# rounds every product before it is added/subtracted (e.g. PrimalSimplexSolver.cs:208).
+// hipcc contracts a*b+c into v_fma_f64 by default; that is one rounding fewer and changes bits,
+// so contraction is off for every translation unit of the engine (also -ffp-contract=off in the
+// Makefile; tests/test_build.py greps the ISA of the update kernels for stray FMAs).
+#pragma clang fp contract(off)
+
+namespace lpr {
+
+constexpr int kWave = 64;
+constexpr int kLdAlign = 16;          // tableau rows padded to 16 doubles = 128 B
+constexpr int32_t kRunning = -100;    // device status word while the pivot loop is live
+
+void set_error(const char* fmt, ...);
+const char* get_error();
+
+#define LPR_HIP(expr)                                                                     \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess) {                                                           \
+            ::lpr::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),       \
+                             __FILE__, __LINE__);                                         \
+            return LPR_DEVICE_ERROR;                                                      \
+        }                                                                                 \
+    } while (0)
+
+inline int align_up(int x, int a) { return (x + a - 1) / a * a; }
+
+// Per-tableau control block in device memory.  Written by the select kernel, read by the update
+// kernel and polled by the host once per batch of pivots (never once per pivot).
+struct PivotState {
+    int32_t status;     // kRunning or an lpr_status
+    int32_t cur_r;      // pivot row of the pending update (tableau row, 1-based constraint index)
+    int32_t cur_e;      // pivot column of the pending update
+    int32_t sweep;      // parity of the update sweep direction (serpentine traversal)
+    int64_t iter;       // pivots performed so far
+    int64_t max_iter;   // stop when iter reaches this (<= 0: no limit)
+    int64_t log_cap;    // capacity of the pivot log in pairs
+};
+
+}  // namespace lpr
+
+struct lpr_engine {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int num_cus = 0;
+    char arch[64] = {0};
+};
+
+struct lpr_tableau {
+    lpr_engine* eng = nullptr;
+    int rows = 0, cols = 0, ld = 0;  // ld = cols rounded up to kLdAlign
+    double* T = nullptr;             // rows x ld, row-major, padding columns kept at 0
+    double* rowbuf = nullptr;        // ld doubles: normalised pivot row
+    double* colbuf = nullptr;        // rows doubles: pivot column before the update
+    int32_t* basis = nullptr;        // rows-1
+    int32_t* log = nullptr;          // 2*log_cap: (row, col) pairs
+    int64_t log_cap = 0;
+    lpr::PivotState* state = nullptr;     // device
+    lpr::PivotState* h_state = nullptr;   // pinned host mirror
+    int32_t* scratch_i = nullptr;    // small device scratch for single-step results
+    int32_t* h_scratch_i = nullptr;  // pinned
+    double* xbuf = nullptr;          // extract-solution output (lazy)
+    int xbuf_n = 0;
+    int64_t total_pivots = 0;
+    // kernel timing (opts.time_kernels)
+    std::vector<hipEvent_t> ev;      // pairs (start, stop)
+    int64_t timed_launches = 0;
+    double timed_total_ms = 0.0;
+    // captured batch of (select, update) pairs
+    hipGraphExec_t graph = nullptr;
+    int graph_batch = 0;
+    int graph_variant = -1;
+};

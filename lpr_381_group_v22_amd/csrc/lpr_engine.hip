@@ -1,0 +1,583 @@
+// lpr_engine.hip -- C ABI (include/lpr_engine.h): engine + full-tableau primal simplex driver.
+// The pivot loop of PrimalSimplexSolver.Solve() (Simplex/PrimalSimplexSolver.cs:102-150) runs on
+// the device: the host only queues batches of (k_select, k_update) pairs and polls one status
+// word per batch.  There is no CPU fallback: without a gfx950 device lpr_engine_open fails.
+#include "engine_common.hpp"
+
+#include <cstdarg>
+#include <new>
+
+#pragma clang fp contract(off)
+
+namespace lpr {
+
+static thread_local std::string g_err;
+
+void set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+const char* get_error() { return g_err.c_str(); }
+
+// primal_kernels.hip
+void launch_select(lpr_tableau* t, int mode, int e_in, int r_in, int32_t* out_i);
+void launch_update(lpr_tableau* t, int variant, int check_status);
+int num_update_variants();
+void launch_extract(lpr_tableau* t, int n, double* x);
+void launch_build(lpr_tableau* t, int n, int m, const double* d_obj, const double* d_A, int lda,
+                  const int32_t* d_ncoef, const int8_t* d_rel, const double* d_rhs, int is_max);
+void launch_synthetic(lpr_tableau* t, int m, int n, uint64_t seed);
+
+enum : int { kSelEnter = 1, kSelLeave = 2, kSelCommit = 4, kSelFull = 7 };
+
+static int alloc_tableau(lpr_engine* e, int rows, int cols, lpr_tableau** out) {
+    if (!e || !out || rows < 1 || cols < 2 || rows > 65535) {
+        set_error("bad tableau shape %d x %d", rows, cols);
+        return LPR_BAD_ARGUMENT;
+    }
+    LPR_HIP(hipSetDevice(e->device));
+    lpr_tableau* t = new (std::nothrow) lpr_tableau();
+    if (!t) return LPR_OUT_OF_MEMORY;
+    t->eng = e;
+    t->rows = rows;
+    t->cols = cols;
+    t->ld = align_up(cols, kLdAlign);
+    t->log_cap = 1 << 16;
+    const size_t tbytes = (size_t)rows * t->ld * sizeof(double);
+    hipError_t err = hipSuccess;
+    auto chk = [&](hipError_t x) { if (err == hipSuccess) err = x; };
+    chk(hipMalloc(&t->T, tbytes));
+    chk(hipMalloc(&t->rowbuf, (size_t)t->ld * sizeof(double)));
+    chk(hipMalloc(&t->colbuf, (size_t)align_up(rows, 16) * sizeof(double)));
+    chk(hipMalloc(&t->basis, (size_t)(rows > 1 ? rows - 1 : 1) * sizeof(int32_t)));
+    chk(hipMalloc(&t->log, (size_t)t->log_cap * 2 * sizeof(int32_t)));
+    chk(hipMalloc(&t->state, sizeof(PivotState)));
+    chk(hipMalloc(&t->scratch_i, 16 * sizeof(int32_t)));
+    chk(hipHostMalloc(&t->h_state, sizeof(PivotState)));
+    chk(hipHostMalloc(&t->h_scratch_i, 16 * sizeof(int32_t)));
+    if (err != hipSuccess) {
+        set_error("device allocation of a %d x %d tableau failed: %s", rows, cols,
+                  hipGetErrorString(err));
+        lpr_tableau_destroy(t);
+        return err == hipErrorOutOfMemory ? LPR_OUT_OF_MEMORY : LPR_DEVICE_ERROR;
+    }
+    std::memset(t->h_state, 0, sizeof(PivotState));
+    t->h_state->status = LPR_OK_OPTIMAL;
+    t->h_state->log_cap = t->log_cap;
+    LPR_HIP(hipMemcpyAsync(t->state, t->h_state, sizeof(PivotState), hipMemcpyHostToDevice,
+                           e->stream));
+    LPR_HIP(hipMemsetAsync(t->T, 0, tbytes, e->stream));
+    LPR_HIP(hipMemsetAsync(t->rowbuf, 0, (size_t)t->ld * sizeof(double), e->stream));
+    *out = t;
+    return LPR_OK_OPTIMAL;
+}
+
+static void drop_graph(lpr_tableau* t) {
+    if (t->graph) {
+        hipGraphExecDestroy(t->graph);
+        t->graph = nullptr;
+    }
+    t->graph_batch = 0;
+    t->graph_variant = -1;
+}
+
+// Grow the pivot log so that `need` pairs fit (keeps the old entries).
+static int ensure_log(lpr_tableau* t, int64_t need) {
+    if (need <= t->log_cap) return LPR_OK_OPTIMAL;
+    int64_t cap = t->log_cap;
+    while (cap < need) cap *= 2;
+    int32_t* nl = nullptr;
+    LPR_HIP(hipMalloc(&nl, (size_t)cap * 2 * sizeof(int32_t)));
+    LPR_HIP(hipMemcpyAsync(nl, t->log, (size_t)t->log_cap * 2 * sizeof(int32_t),
+                           hipMemcpyDeviceToDevice, t->eng->stream));
+    LPR_HIP(hipStreamSynchronize(t->eng->stream));
+    LPR_HIP(hipFree(t->log));
+    t->log = nl;
+    t->log_cap = cap;
+    drop_graph(t);  // the log pointer is a captured kernel argument
+    return LPR_OK_OPTIMAL;
+}
+
+static int default_variant(const lpr_tableau* t) {
+    (void)t;
+    return 0;
+}
+
+static int default_batch(const lpr_tableau* t) {
+    // aim at a few milliseconds of device work between host polls
+    const double bytes = 16.0 * t->rows * (double)t->ld;
+    const double us = bytes / 4.0e6 + 6.0;  // ~4 TB/s + select/launch overhead
+    int b = (int)(4000.0 / us);
+    if (b < 8) b = 8;
+    if (b > 512) b = 512;
+    return b;
+}
+
+}  // namespace lpr
+
+using namespace lpr;
+
+extern "C" {
+
+int lpr_abi_version(void) { return LPR_ABI_VERSION; }
+
+const char* lpr_last_error(void) { return get_error(); }
+
+int lpr_engine_open(int device, lpr_engine** out) {
+    if (!out) return LPR_BAD_ARGUMENT;
+    *out = nullptr;
+    int count = 0;
+    hipError_t err = hipGetDeviceCount(&count);
+    if (err != hipSuccess || count <= 0) {
+        set_error("no HIP device available (%s); this engine has no CPU fallback",
+                  err == hipSuccess ? "device count is 0" : hipGetErrorString(err));
+        return LPR_DEVICE_ERROR;
+    }
+    if (device < 0 || device >= count) {
+        set_error("device %d out of range (0..%d)", device, count - 1);
+        return LPR_BAD_ARGUMENT;
+    }
+    LPR_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    LPR_HIP(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("device %d is %s; this engine is built for gfx950 only", device,
+                  prop.gcnArchName);
+        return LPR_DEVICE_ERROR;
+    }
+    lpr_engine* e = new (std::nothrow) lpr_engine();
+    if (!e) return LPR_OUT_OF_MEMORY;
+    e->device = device;
+    e->num_cus = prop.multiProcessorCount;
+    std::snprintf(e->arch, sizeof e->arch, "%s", prop.gcnArchName);
+    hipError_t serr = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    if (serr != hipSuccess) {
+        set_error("hipStreamCreate failed: %s", hipGetErrorString(serr));
+        delete e;
+        return LPR_DEVICE_ERROR;
+    }
+    *out = e;
+    return LPR_OK_OPTIMAL;
+}
+
+int lpr_engine_close(lpr_engine* e) {
+    if (!e) return LPR_BAD_ARGUMENT;
+    hipSetDevice(e->device);
+    if (e->stream) {
+        hipStreamSynchronize(e->stream);
+        hipStreamDestroy(e->stream);
+    }
+    delete e;
+    return LPR_OK_OPTIMAL;
+}
+
+int lpr_engine_sync(lpr_engine* e) {
+    if (!e) return LPR_BAD_ARGUMENT;
+    LPR_HIP(hipStreamSynchronize(e->stream));
+    return LPR_OK_OPTIMAL;
+}
+
+uint64_t lpr_engine_stream(lpr_engine* e) { return e ? (uint64_t)(uintptr_t)e->stream : 0; }
+
+// ------------------------------------------------------------------------------ tableau
+
+int lpr_tableau_from_lp(lpr_engine* e, int n, int m, const double* objective, const double* A,
+                        int lda, const int32_t* ncoef, const int8_t* relation, const double* rhs,
+                        int is_max, lpr_tableau** out) {
+    if (!e || !out || n < 0 || m < 0 || (n > 0 && !objective) || (m > 0 && (!rhs || lda < n)) ||
+        (m > 0 && n > 0 && !A)) {
+        set_error("lpr_tableau_from_lp: bad arguments (n=%d m=%d lda=%d)", n, m, lda);
+        return LPR_BAD_ARGUMENT;
+    }
+    lpr_tableau* t = nullptr;
+    int rc = alloc_tableau(e, m + 1, n + m + 1, &t);
+    if (rc != LPR_OK_OPTIMAL) return rc;
+    hipStream_t s = e->stream;
+    double *d_obj = nullptr, *d_A = nullptr, *d_rhs = nullptr;
+    int32_t* d_ncoef = nullptr;
+    int8_t* d_rel = nullptr;
+    hipError_t err = hipSuccess;
+    auto chk = [&](hipError_t x) { if (err == hipSuccess) err = x; };
+    if (n > 0) {
+        chk(hipMalloc(&d_obj, (size_t)n * sizeof(double)));
+        if (err == hipSuccess)
+            chk(hipMemcpyAsync(d_obj, objective, (size_t)n * sizeof(double),
+                               hipMemcpyHostToDevice, s));
+    }
+    if (m > 0) {
+        if (n > 0) {
+            chk(hipMalloc(&d_A, (size_t)m * n * sizeof(double)));
+            if (err == hipSuccess)
+                chk(hipMemcpy2DAsync(d_A, (size_t)n * sizeof(double), A,
+                                     (size_t)lda * sizeof(double), (size_t)n * sizeof(double), m,
+                                     hipMemcpyHostToDevice, s));
+        }
+        chk(hipMalloc(&d_rhs, (size_t)m * sizeof(double)));
+        if (err == hipSuccess)
+            chk(hipMemcpyAsync(d_rhs, rhs, (size_t)m * sizeof(double), hipMemcpyHostToDevice, s));
+        if (ncoef) {
+            chk(hipMalloc(&d_ncoef, (size_t)m * sizeof(int32_t)));
+            if (err == hipSuccess)
+                chk(hipMemcpyAsync(d_ncoef, ncoef, (size_t)m * sizeof(int32_t),
+                                   hipMemcpyHostToDevice, s));
+        }
+        if (relation) {
+            chk(hipMalloc(&d_rel, (size_t)m));
+            if (err == hipSuccess)
+                chk(hipMemcpyAsync(d_rel, relation, (size_t)m, hipMemcpyHostToDevice, s));
+        }
+    }
+    if (err == hipSuccess) {
+        launch_build(t, n, m, d_obj, d_A, n, d_ncoef, d_rel, d_rhs, is_max);
+        chk(hipGetLastError());
+        chk(hipStreamSynchronize(s));  // inputs are borrowed for this call only
+    }
+    hipFree(d_obj);
+    hipFree(d_A);
+    hipFree(d_rhs);
+    hipFree(d_ncoef);
+    hipFree(d_rel);
+    if (err != hipSuccess) {
+        set_error("lpr_tableau_from_lp: %s", hipGetErrorString(err));
+        lpr_tableau_destroy(t);
+        return LPR_DEVICE_ERROR;
+    }
+    *out = t;
+    return LPR_OK_OPTIMAL;
+}
+
+int lpr_tableau_create(lpr_engine* e, int rows, int cols, const double* rowmajor,
+                       const int32_t* basis, lpr_tableau** out) {
+    if (!e || !out || !rowmajor) {
+        set_error("lpr_tableau_create: null argument");
+        return LPR_BAD_ARGUMENT;
+    }
+    lpr_tableau* t = nullptr;
+    int rc = alloc_tableau(e, rows, cols, &t);
+    if (rc != LPR_OK_OPTIMAL) return rc;
+    hipStream_t s = e->stream;
+    hipError_t err = hipMemcpy2DAsync(t->T, (size_t)t->ld * sizeof(double), rowmajor,
+                                      (size_t)cols * sizeof(double), (size_t)cols * sizeof(double),
+                                      rows, hipMemcpyHostToDevice, s);
+    if (err == hipSuccess && rows > 1) {
+        if (basis)
+            err = hipMemcpyAsync(t->basis, basis, (size_t)(rows - 1) * sizeof(int32_t),
+                                 hipMemcpyHostToDevice, s);
+        else
+            err = hipMemsetAsync(t->basis, 0xff, (size_t)(rows - 1) * sizeof(int32_t), s);
+    }
+    if (err == hipSuccess) err = hipStreamSynchronize(s);
+    if (err != hipSuccess) {
+        set_error("lpr_tableau_create: %s", hipGetErrorString(err));
+        lpr_tableau_destroy(t);
+        return LPR_DEVICE_ERROR;
+    }
+    *out = t;
+    return LPR_OK_OPTIMAL;
+}
+
+int lpr_tableau_synthetic(lpr_engine* e, int m, int n, uint64_t seed, lpr_tableau** out) {
+    if (!e || !out || m < 1 || n < 1) {
+        set_error("lpr_tableau_synthetic: bad arguments (m=%d n=%d)", m, n);
+        return LPR_BAD_ARGUMENT;
+    }
+    lpr_tableau* t = nullptr;
+    int rc = alloc_tableau(e, m + 1, n + m + 1, &t);
+    if (rc != LPR_OK_OPTIMAL) return rc;
+    launch_synthetic(t, m, n, seed);
+    hipError_t err = hipGetLastError();
+    if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+    if (err != hipSuccess) {
+        set_error("lpr_tableau_synthetic: %s", hipGetErrorString(err));
+        lpr_tableau_destroy(t);
+        return LPR_DEVICE_ERROR;
+    }
+    *out = t;
+    return LPR_OK_OPTIMAL;
+}
+
+int lpr_tableau_destroy(lpr_tableau* t) {
+    if (!t) return LPR_BAD_ARGUMENT;
+    if (t->eng) {
+        hipSetDevice(t->eng->device);
+        if (t->eng->stream) hipStreamSynchronize(t->eng->stream);
+    }
+    drop_graph(t);
+    for (hipEvent_t ev : t->ev) hipEventDestroy(ev);
+    hipFree(t->T);
+    hipFree(t->rowbuf);
+    hipFree(t->colbuf);
+    hipFree(t->basis);
+    hipFree(t->log);
+    hipFree(t->state);
+    hipFree(t->scratch_i);
+    hipFree(t->xbuf);
+    if (t->h_state) hipHostFree(t->h_state);
+    if (t->h_scratch_i) hipHostFree(t->h_scratch_i);
+    delete t;
+    return LPR_OK_OPTIMAL;
+}
+
+int lpr_tableau_shape(const lpr_tableau* t, int* rows, int* cols, int* ld) {
+    if (!t) return LPR_BAD_ARGUMENT;
+    if (rows) *rows = t->rows;
+    if (cols) *cols = t->cols;
+    if (ld) *ld = t->ld;
+    return LPR_OK_OPTIMAL;
+}
+
+// ------------------------------------------------------------------------------ solve
+
+int lpr_primal_solve(lpr_tableau* t, const lpr_solve_opts* opts, lpr_solve_result* res) {
+    if (!t || !res) {
+        set_error("lpr_primal_solve: null argument");
+        return LPR_BAD_ARGUMENT;
+    }
+    lpr_solve_opts o;
+    std::memset(&o, 0, sizeof o);
+    if (opts) o = *opts;
+    lpr_engine* e = t->eng;
+    hipStream_t s = e->stream;
+    LPR_HIP(hipSetDevice(e->device));
+
+    const int variant = o.variant > 0 ? o.variant - 1 : default_variant(t);
+    int batch = o.batch > 0 ? o.batch : default_batch(t);
+    const bool timed = o.time_kernels != 0;
+    const int64_t start_iter = t->total_pivots;
+    const int64_t max_iter = o.max_pivots > 0 ? start_iter + o.max_pivots : 0;
+
+    PivotState* hs = t->h_state;
+    hs->status = kRunning;
+    hs->iter = start_iter;
+    hs->max_iter = max_iter;
+    hs->log_cap = t->log_cap;
+    // cur_r/cur_e/sweep keep their device values: upload everything except those via two copies
+    LPR_HIP(hipMemcpyAsync(&t->state->status, &hs->status, sizeof(int32_t), hipMemcpyHostToDevice,
+                           s));
+    LPR_HIP(hipMemcpyAsync(&t->state->iter, &hs->iter, 3 * sizeof(int64_t),
+                           hipMemcpyHostToDevice, s));
+
+    int status = kRunning;
+    int64_t iter = start_iter;
+    while (status == kRunning) {
+        int nb = batch;
+        if (timed && max_iter > 0) {
+            const int64_t left = max_iter - iter;
+            if (left < nb) nb = (int)left;  // may be 0: then only the closing select runs
+        }
+        int rc = ensure_log(t, iter + nb + 1);
+        if (rc != LPR_OK_OPTIMAL) return rc;
+        if (t->log_cap != hs->log_cap) {
+            hs->log_cap = t->log_cap;
+            LPR_HIP(hipMemcpyAsync(&t->state->log_cap, &hs->log_cap, sizeof(int64_t),
+                                   hipMemcpyHostToDevice, s));
+        }
+
+        if (timed) {
+            while ((int)t->ev.size() < 2 * nb) {
+                hipEvent_t ev;
+                LPR_HIP(hipEventCreate(&ev));
+                t->ev.push_back(ev);
+            }
+            for (int k = 0; k < nb; ++k) {
+                launch_select(t, kSelFull, -1, -1, nullptr);
+                LPR_HIP(hipEventRecord(t->ev[2 * k], s));
+                launch_update(t, variant, 1);
+                LPR_HIP(hipEventRecord(t->ev[2 * k + 1], s));
+            }
+            if (nb == 0 || (max_iter > 0 && iter + nb >= max_iter))
+                launch_select(t, kSelFull, -1, -1, nullptr);  // closing loop head -> final status
+        } else {
+            if (!t->graph || t->graph_batch != nb || t->graph_variant != variant) {
+                drop_graph(t);
+                hipGraph_t g = nullptr;
+                LPR_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+                for (int k = 0; k < nb; ++k) {
+                    launch_select(t, kSelFull, -1, -1, nullptr);
+                    launch_update(t, variant, 1);
+                }
+                LPR_HIP(hipStreamEndCapture(s, &g));
+                hipError_t ierr = hipGraphInstantiate(&t->graph, g, nullptr, nullptr, 0);
+                hipGraphDestroy(g);
+                if (ierr != hipSuccess) {
+                    t->graph = nullptr;
+                    set_error("hipGraphInstantiate failed: %s", hipGetErrorString(ierr));
+                    return LPR_DEVICE_ERROR;
+                }
+                t->graph_batch = nb;
+                t->graph_variant = variant;
+            }
+            LPR_HIP(hipGraphLaunch(t->graph, s));
+        }
+        LPR_HIP(hipGetLastError());
+        LPR_HIP(hipMemcpyAsync(hs, t->state, sizeof(PivotState), hipMemcpyDeviceToHost, s));
+        LPR_HIP(hipStreamSynchronize(s));
+        const int64_t done = hs->iter - iter;
+        if (timed) {
+            for (int64_t k = 0; k < done && k < nb; ++k) {  // only launches that really pivoted
+                float ms = 0.f;
+                LPR_HIP(hipEventElapsedTime(&ms, t->ev[2 * k], t->ev[2 * k + 1]));
+                t->timed_total_ms += ms;
+                t->timed_launches += 1;
+            }
+        }
+        iter = hs->iter;
+        status = hs->status;
+        if (status == kRunning && done == 0 && nb > 0) {
+            set_error("pivot loop made no progress (device status still running)");
+            return LPR_DEVICE_ERROR;
+        }
+    }
+    t->total_pivots = iter;
+    res->status = status;
+    res->reserved = 0;
+    res->pivots = iter - start_iter;
+    res->total_pivots = iter;
+    double z = 0.0;
+    LPR_HIP(hipMemcpyAsync(&z, t->T + (t->cols - 1), sizeof(double), hipMemcpyDeviceToHost, s));
+    LPR_HIP(hipStreamSynchronize(s));
+    res->z = z;
+    return status;
+}
+
+static int read_scratch(lpr_tableau* t, int idx, int32_t* out) {
+    hipStream_t s = t->eng->stream;
+    LPR_HIP(hipGetLastError());
+    LPR_HIP(hipMemcpyAsync(t->h_scratch_i, t->scratch_i, 4 * sizeof(int32_t),
+                           hipMemcpyDeviceToHost, s));
+    LPR_HIP(hipStreamSynchronize(s));
+    *out = t->h_scratch_i[idx];
+    return LPR_OK_OPTIMAL;
+}
+
+int lpr_select_entering(lpr_tableau* t, int32_t* col) {
+    if (!t || !col) return LPR_BAD_ARGUMENT;
+    LPR_HIP(hipSetDevice(t->eng->device));
+    launch_select(t, kSelEnter, -1, -1, t->scratch_i);
+    return read_scratch(t, 0, col);
+}
+
+int lpr_select_leaving(lpr_tableau* t, int32_t col, int32_t* row) {
+    if (!t || !row || col < 0 || col >= t->cols - 1) {
+        set_error("lpr_select_leaving: column %d out of range", col);
+        return LPR_BAD_ARGUMENT;
+    }
+    LPR_HIP(hipSetDevice(t->eng->device));
+    launch_select(t, kSelLeave, col, -1, t->scratch_i);
+    return read_scratch(t, 1, row);
+}
+
+int lpr_pivot(lpr_tableau* t, int32_t row, int32_t col) {
+    if (!t || row < 1 || row >= t->rows || col < 0 || col >= t->cols) {
+        set_error("lpr_pivot: (%d, %d) out of range", row, col);
+        return LPR_BAD_ARGUMENT;
+    }
+    LPR_HIP(hipSetDevice(t->eng->device));
+    int rc = ensure_log(t, t->total_pivots + 1);
+    if (rc != LPR_OK_OPTIMAL) return rc;
+    hipStream_t s = t->eng->stream;
+    PivotState* hs = t->h_state;
+    hs->iter = t->total_pivots;
+    hs->max_iter = 0;
+    hs->log_cap = t->log_cap;
+    LPR_HIP(hipMemcpyAsync(&t->state->iter, &hs->iter, 3 * sizeof(int64_t),
+                           hipMemcpyHostToDevice, s));
+    launch_select(t, kSelCommit, col, row, nullptr);
+    launch_update(t, default_variant(t), 0);
+    LPR_HIP(hipGetLastError());
+    LPR_HIP(hipStreamSynchronize(s));
+    t->total_pivots += 1;
+    return LPR_OK_OPTIMAL;
+}
+
+int lpr_extract_solution(lpr_tableau* t, int n, double* x, double* z) {
+    if (!t || n < 0 || n > t->cols - 1 || (n > 0 && !x)) {
+        set_error("lpr_extract_solution: bad arguments (n=%d)", n);
+        return LPR_BAD_ARGUMENT;
+    }
+    LPR_HIP(hipSetDevice(t->eng->device));
+    hipStream_t s = t->eng->stream;
+    if (n > 0) {
+        if (t->xbuf_n < n) {
+            hipFree(t->xbuf);
+            t->xbuf = nullptr;
+            t->xbuf_n = 0;
+            LPR_HIP(hipMalloc(&t->xbuf, (size_t)n * sizeof(double)));
+            t->xbuf_n = n;
+        }
+        launch_extract(t, n, t->xbuf);
+        LPR_HIP(hipGetLastError());
+        LPR_HIP(hipMemcpyAsync(x, t->xbuf, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
+    }
+    if (z)
+        LPR_HIP(hipMemcpyAsync(z, t->T + (t->cols - 1), sizeof(double), hipMemcpyDeviceToHost,
+                               s));
+    LPR_HIP(hipStreamSynchronize(s));
+    return LPR_OK_OPTIMAL;
+}
+
+int lpr_tableau_read_block(lpr_tableau* t, int row0, int nrows, int col0, int ncols,
+                           double* out) {
+    if (!t || !out || row0 < 0 || col0 < 0 || nrows < 0 || ncols < 0 ||
+        row0 + nrows > t->rows || col0 + ncols > t->cols) {
+        set_error("lpr_tableau_read_block: block out of range");
+        return LPR_BAD_ARGUMENT;
+    }
+    if (nrows == 0 || ncols == 0) return LPR_OK_OPTIMAL;
+    LPR_HIP(hipSetDevice(t->eng->device));
+    hipStream_t s = t->eng->stream;
+    LPR_HIP(hipMemcpy2DAsync(out, (size_t)ncols * sizeof(double),
+                             t->T + (size_t)row0 * t->ld + col0, (size_t)t->ld * sizeof(double),
+                             (size_t)ncols * sizeof(double), nrows, hipMemcpyDeviceToHost, s));
+    LPR_HIP(hipStreamSynchronize(s));
+    return LPR_OK_OPTIMAL;
+}
+
+int lpr_tableau_read(lpr_tableau* t, double* rowmajor_out) {
+    if (!t) return LPR_BAD_ARGUMENT;
+    return lpr_tableau_read_block(t, 0, t->rows, 0, t->cols, rowmajor_out);
+}
+
+int lpr_basis_read(lpr_tableau* t, int32_t* basis_out) {
+    if (!t || !basis_out) return LPR_BAD_ARGUMENT;
+    if (t->rows <= 1) return LPR_OK_OPTIMAL;
+    LPR_HIP(hipSetDevice(t->eng->device));
+    hipStream_t s = t->eng->stream;
+    LPR_HIP(hipMemcpyAsync(basis_out, t->basis, (size_t)(t->rows - 1) * sizeof(int32_t),
+                           hipMemcpyDeviceToHost, s));
+    LPR_HIP(hipStreamSynchronize(s));
+    return LPR_OK_OPTIMAL;
+}
+
+int lpr_pivot_log_read(lpr_tableau* t, int32_t* rows_out, int32_t* cols_out, int64_t cap,
+                       int64_t* count) {
+    if (!t || !count || cap < 0) return LPR_BAD_ARGUMENT;
+    int64_t n = t->total_pivots < t->log_cap ? t->total_pivots : t->log_cap;
+    if (n > cap) n = cap;
+    *count = n;
+    if (n == 0) return LPR_OK_OPTIMAL;
+    LPR_HIP(hipSetDevice(t->eng->device));
+    std::vector<int32_t> tmp((size_t)n * 2);
+    LPR_HIP(hipMemcpy(tmp.data(), t->log, (size_t)n * 2 * sizeof(int32_t),
+                      hipMemcpyDeviceToHost));
+    for (int64_t k = 0; k < n; ++k) {
+        if (rows_out) rows_out[k] = tmp[2 * k];
+        if (cols_out) cols_out[k] = tmp[2 * k + 1];
+    }
+    return LPR_OK_OPTIMAL;
+}
+
+int lpr_tableau_kernel_stats(lpr_tableau* t, int64_t* launches, double* total_ms,
+                             double* avg_ms) {
+    if (!t) return LPR_BAD_ARGUMENT;
+    if (launches) *launches = t->timed_launches;
+    if (total_ms) *total_ms = t->timed_total_ms;
+    if (avg_ms) *avg_ms = t->timed_launches ? t->timed_total_ms / t->timed_launches : 0.0;
+    return LPR_OK_OPTIMAL;
+}
+
+}  // extern "C"

@@ -1,0 +1,412 @@
+// primal_kernels.hip -- gfx950 kernels of the full-tableau primal simplex pivot
+// (reference: LPR_381_Group_V22/Simplex/PrimalSimplexSolver.cs).
+//
+// Data layout in HBM: the (m+1) x (n+m+1) fp64 tableau is row-major like the C# double[,], with
+// the leading dimension padded to 16 doubles so every row starts on a 128-byte line and the
+// streaming kernel can use 16 B/lane loads and stores.  Padding columns are kept at 0.
+//
+//   k_select  one workgroup: FindEnteringVariable (:152-167) as a wave64 shuffle arg-min,
+//             FindLeavingVariable (:169-191) over the two strided columns, then the pivot-row
+//             normalise (:198-199) into a dense scratch row and the pivot column into a dense
+//             scratch column, basis + pivot-log update (:142).  Sets the device status word.
+//   k_update  the roofline kernel: rank-1 row elimination (:202-210), every element read once
+//             and written once (2*8*R*C algorithmic bytes), HBM-bound.
+//   k_extract ExtractSolution (:213-252), one lane per decision column.
+//   k_build*  the constructor (:27-87) and the synthetic benchmark LP.
+#include "engine_common.hpp"
+
+#pragma clang fp contract(off)
+
+namespace lpr {
+
+// ------------------------------------------------------------------------------------------
+// (value, index) lexicographic arg-min.  i < 0 == "no candidate".  Both C# scans keep a candidate
+// only when it is STRICTLY below the running best, so the sequential result is the minimum value
+// at its lowest index -- which is exactly the lexicographic minimum, and that is associative and
+// commutative, so a tree reduction gives the same answer as the C# loop.
+struct Cand {
+    double v;
+    int i;
+};
+
+__device__ __forceinline__ Cand cand_min(Cand a, Cand b) {
+    if (b.i < 0) return a;
+    if (a.i < 0) return b;
+    if (b.v < a.v || (b.v == a.v && b.i < a.i)) return b;
+    return a;
+}
+
+__device__ __forceinline__ Cand wave_cand_min(Cand c) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        Cand o;
+        o.v = __shfl_xor(c.v, off, kWave);
+        o.i = __shfl_xor(c.i, off, kWave);
+        c = cand_min(c, o);
+    }
+    return c;
+}
+
+// All threads of the block receive the block-wide minimum.  lds_v/lds_i hold one slot per wave.
+__device__ __forceinline__ Cand block_cand_min(Cand c, double* lds_v, int* lds_i) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    const int nwaves = blockDim.x / kWave;
+    c = wave_cand_min(c);
+    __syncthreads();  // protect the slots against the previous use
+    if (lane == 0) {
+        lds_v[wave] = c.v;
+        lds_i[wave] = c.i;
+    }
+    __syncthreads();
+    Cand r;
+    r.v = lds_v[0];
+    r.i = lds_i[0];
+    for (int w = 1; w < nwaves; ++w) {
+        Cand o;
+        o.v = lds_v[w];
+        o.i = lds_i[w];
+        r = cand_min(r, o);
+    }
+    return r;
+}
+
+enum : int { kSelEnter = 1, kSelLeave = 2, kSelCommit = 4, kSelFull = 7 };
+
+// One workgroup of 1024 threads.  In kSelFull mode this is "one C# loop head": it either ends the
+// solve (status word) or leaves (cur_r, cur_e, rowbuf, colbuf) ready for k_update.
+__global__ __launch_bounds__(1024) void k_select(double* __restrict__ T, int ld, int R, int C,
+                                                 double* __restrict__ rowbuf,
+                                                 double* __restrict__ colbuf,
+                                                 int32_t* __restrict__ basis,
+                                                 int32_t* __restrict__ log, PivotState* st,
+                                                 int mode, int e_in, int r_in,
+                                                 int32_t* __restrict__ out_i) {
+    __shared__ double lds_v[16];
+    __shared__ int lds_i[16];
+    const int tid = threadIdx.x;
+    const int nt = blockDim.x;
+    const bool full = (mode == kSelFull);
+
+    if (full && st->status != kRunning) return;
+
+    int e = e_in;
+    int r = r_in;
+
+    // ---- FindEnteringVariable  PrimalSimplexSolver.cs:152-167 ----
+    if (mode & kSelEnter) {
+        Cand c;
+        c.v = 0.0;  // mostNegative = 0
+        c.i = -1;
+        for (int j = tid; j < C - 1; j += nt) {
+            double v = T[j];
+            if (v < c.v) {  // strict: ties keep the lower index, NaN and -0 never enter
+                c.v = v;
+                c.i = j;
+            }
+        }
+        c = block_cand_min(c, lds_v, lds_i);
+        e = c.i;
+        if (tid == 0 && out_i) out_i[0] = e;
+        if (e < 0) {
+            if (full && tid == 0) st->status = LPR_OK_OPTIMAL;  // :110-126
+            return;
+        }
+    }
+
+    // ---- FindLeavingVariable  PrimalSimplexSolver.cs:169-191 ----
+    // The same pass copies column e (all rows, row 0 included) into colbuf: the factors
+    // `tableau[i, pivotCol]` that Pivot reads before it overwrites the row (:206).
+    const bool gather_in_leave = (mode & kSelLeave) != 0;
+    if (mode & kSelLeave) {
+        Cand c;
+        c.v = DBL_MAX;  // double.MaxValue
+        c.i = -1;
+        const int rhs = C - 1;
+        for (int i = tid; i < R; i += nt) {
+            const double a = T[(size_t)i * ld + e];
+            colbuf[i] = a;
+            if (i >= 1 && a > 1e-9) {
+                const double ratio = T[(size_t)i * ld + rhs] / a;  // IEEE division
+                if (ratio >= 0 && ratio < c.v) {
+                    c.v = ratio;
+                    c.i = i;
+                }
+            }
+        }
+        c = block_cand_min(c, lds_v, lds_i);
+        r = c.i;
+        if (tid == 0 && out_i) out_i[1] = r;
+        if (r < 0) {
+            if (full && tid == 0) st->status = LPR_UNBOUNDED;  // :129-135
+            return;
+        }
+    }
+
+    if (!(mode & kSelCommit)) return;
+
+    if (full) {
+        const int64_t it = st->iter;
+        const int64_t mx = st->max_iter;
+        if (mx > 0 && it >= mx) {
+            if (tid == 0) st->status = LPR_PIVOT_LIMIT;
+            return;
+        }
+    }
+
+    // ---- Pivot, first half  PrimalSimplexSolver.cs:195-199 ----
+    // rowbuf[j] = T[r, j] / T[r, e] (true division).  The row itself is rewritten by k_update.
+    const double p = T[(size_t)r * ld + e];
+    const double* prow = T + (size_t)r * ld;
+    for (int j = tid; j < ld; j += nt) rowbuf[j] = (j < C) ? prow[j] / p : 0.0;
+    if (!gather_in_leave) {
+        for (int i = tid; i < R; i += nt) colbuf[i] = T[(size_t)i * ld + e];
+    }
+
+    if (tid == 0) {
+        st->cur_r = r;
+        st->cur_e = e;
+        basis[r - 1] = e;  // :142
+        const int64_t it = st->iter;
+        if (it < st->log_cap) {
+            log[2 * it] = r;
+            log[2 * it + 1] = e;
+        }
+        st->iter = it + 1;  // :138 ++iteration
+        st->sweep ^= 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Rank-1 row elimination  PrimalSimplexSolver.cs:202-210
+//   T[i, j] = T[i, j] - (f_i * prow[j])   for i != r      (product rounded, then difference)
+//   T[r, j] = prow[j]                                       (the normalised row, :199)
+// Tile = TR rows x (256*VPT) double2 columns per 256-thread workgroup.  Each lane keeps its slice
+// of the normalised pivot row in registers for the whole tile, the per-row factor f_i is a
+// wave-uniform scalar load, and all TR*VPT 16-byte loads of a lane are issued before the first
+// store so a wave has TR*VPT KiB in flight.
+template <int TR, int VPT, bool FULL>
+__device__ __forceinline__ void update_tile(double2* __restrict__ T2, int ld2, int R, int r,
+                                            const double2* __restrict__ prow2,
+                                            const double* __restrict__ colbuf, int i0,
+                                            int c2base) {
+    double2 pr[VPT];
+    bool ok[VPT];
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) {
+        const int c2 = c2base + v * 256;
+        ok[v] = FULL || c2 < ld2;
+        pr[v] = ok[v] ? prow2[c2] : make_double2(0.0, 0.0);
+    }
+    double2 x[TR][VPT];
+#pragma unroll
+    for (int k = 0; k < TR; ++k) {
+        const int i = i0 + k;
+        if (FULL || i < R) {
+#pragma unroll
+            for (int v = 0; v < VPT; ++v)
+                if (ok[v]) x[k][v] = T2[(size_t)i * ld2 + c2base + v * 256];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < TR; ++k) {
+        const int i = i0 + k;
+        if (FULL || i < R) {
+            const double f = colbuf[i];
+            const bool is_r = (i == r);
+#pragma unroll
+            for (int v = 0; v < VPT; ++v) {
+                if (ok[v]) {
+                    double2 o;
+                    const double px = f * pr[v].x;  // product rounded ...
+                    const double py = f * pr[v].y;
+                    o.x = x[k][v].x - px;           // ... then the difference (:208)
+                    o.y = x[k][v].y - py;
+                    if (is_r) o = pr[v];            // the pivot row keeps the normalised values
+                    T2[(size_t)i * ld2 + c2base + v * 256] = o;
+                }
+            }
+        }
+    }
+}
+
+template <int TR, int VPT>
+__global__ __launch_bounds__(256) void k_update(double* __restrict__ T, int ld, int R,
+                                                const double* __restrict__ rowbuf,
+                                                const double* __restrict__ colbuf,
+                                                const PivotState* __restrict__ st,
+                                                int check_status, int serpentine) {
+    if (check_status && st->status != kRunning) return;
+    const int r = st->cur_r;
+    const int ld2 = ld >> 1;
+    int ct = blockIdx.x, rt = blockIdx.y;
+    if (serpentine && (st->sweep & 1)) {  // reverse the sweep on alternate pivots
+        ct = gridDim.x - 1 - ct;
+        rt = gridDim.y - 1 - rt;
+    }
+    const int c2base = ct * (256 * VPT) + threadIdx.x;
+    const double2* __restrict__ prow2 = reinterpret_cast<const double2*>(rowbuf);
+    double2* __restrict__ T2 = reinterpret_cast<double2*>(T);
+    const int i0 = rt * TR;
+    // interior tiles (the common case) run without any per-element guard
+    const bool full = (i0 + TR <= R) && ((ct + 1) * (256 * VPT) <= ld2);
+    if (full)
+        update_tile<TR, VPT, true>(T2, ld2, R, r, prow2, colbuf, i0, c2base);
+    else
+        update_tile<TR, VPT, false>(T2, ld2, R, r, prow2, colbuf, i0, c2base);
+}
+
+// ------------------------------------------------------------------------------------------
+// ExtractSolution  PrimalSimplexSolver.cs:213-252.  One lane per decision column j < n (coalesced
+// across j), serial over rows.  The C# early `break`s only stop the scan; the verdict
+// "exactly one entry within 1e-9 of 1 and every other entry within 1e-9 of 0" does not depend on
+// where the scan stops, so the full scan gives the same x_j.
+__global__ __launch_bounds__(256) void k_extract(const double* __restrict__ T, int ld, int R,
+                                                 int C, int n, double* __restrict__ x) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    int basicRow = -1;
+    bool isBasic = true;
+    for (int i = 1; i < R; ++i) {
+        const double v = T[(size_t)i * ld + j];
+        if (fabs(v - 1.0) < 1e-9) {
+            if (basicRow == -1) basicRow = i;
+            else isBasic = false;
+        } else if (fabs(v) > 1e-9) {
+            isBasic = false;
+        }
+    }
+    x[j] = (isBasic && basicRow != -1) ? T[(size_t)basicRow * ld + (C - 1)] : 0.0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Constructor  PrimalSimplexSolver.cs:27-87 (T is zero-filled before this kernel runs).
+__global__ __launch_bounds__(256) void k_build_rows(double* __restrict__ T, int ld, int n, int m,
+                                                    const double* __restrict__ A, int lda,
+                                                    const int32_t* __restrict__ ncoef,
+                                                    const int8_t* __restrict__ rel,
+                                                    const double* __restrict__ rhs,
+                                                    int32_t* __restrict__ basis) {
+    const int i = blockIdx.y;  // constraint row
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const bool ge = rel && rel[i] == LPR_REL_GE;  // :36-41
+    const int cnt = ncoef ? ncoef[i] : n;
+    double* row = T + (size_t)(i + 1) * ld;
+    if (j < n && j < cnt) {  // :68-72
+        const double a = A[(size_t)i * lda + j];
+        row[j] = ge ? -a : a;
+    }
+    if (j == 0) {
+        const int C = n + m + 1;
+        row[n + i] = 1.0;                   // :75-76
+        basis[i] = n + i;                   // :78
+        row[C - 1] = ge ? -rhs[i] : rhs[i]; // :82
+    }
+}
+
+__global__ __launch_bounds__(256) void k_build_obj(double* __restrict__ T, int n,
+                                                   const double* __restrict__ obj, int is_max) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) T[j] = is_max ? -obj[j] : obj[j];  // :61-62
+}
+
+// Synthetic dense LP (DESIGN.md "benchmark input"): same SplitMix64-keyed function as
+// oracle/oracle_primal.c:orc_u01, evaluated per element on the device.
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ULL;
+    uint64_t z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ double u01(uint64_t seed, uint64_t stream, uint64_t i, uint64_t j) {
+    uint64_t k = splitmix64(seed ^ (stream * 0xD1B54A32D192ED03ULL));
+    k = splitmix64(k + i);
+    k = splitmix64(k + j);
+    return (double)(k >> 11) * 0x1.0p-53;
+}
+
+__global__ __launch_bounds__(256) void k_synthetic(double* __restrict__ T, int ld, int m, int n,
+                                                   uint64_t seed, int32_t* __restrict__ basis) {
+    const int i = blockIdx.y;  // tableau row
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ld) return;
+    const int C = n + m + 1;
+    double v = 0.0;
+    if (i == 0) {
+        if (j < n) v = -u01(seed, 2, 0, (uint64_t)j);
+    } else {
+        const int ci = i - 1;
+        if (j < n) v = u01(seed, 0, (uint64_t)ci, (uint64_t)j);
+        else if (j == n + ci) v = 1.0;
+        else if (j == C - 1) {
+            const double u = u01(seed, 1, (uint64_t)ci, 0);
+            const double s = u * ((double)n * 0.25);
+            v = 1.0 + s;
+        }
+        if (j == 0) basis[ci] = n + ci;
+    }
+    T[(size_t)i * ld + j] = v;
+}
+
+// ------------------------------------------------------------------------------------------
+// Host-side launchers (called from lpr_engine.hip).
+
+void launch_select(lpr_tableau* t, int mode, int e_in, int r_in, int32_t* out_i) {
+    hipLaunchKernelGGL(k_select, dim3(1), dim3(1024), 0, t->eng->stream, t->T, t->ld, t->rows,
+                       t->cols, t->rowbuf, t->colbuf, t->basis, t->log, t->state, mode, e_in,
+                       r_in, out_i);
+}
+
+template <int TR, int VPT>
+static void launch_update_t(lpr_tableau* t, int check_status, int serpentine) {
+    const int ld2 = t->ld / 2;
+    dim3 grid((ld2 + 256 * VPT - 1) / (256 * VPT), (t->rows + TR - 1) / TR);
+    hipLaunchKernelGGL((k_update<TR, VPT>), grid, dim3(256), 0, t->eng->stream, t->T, t->ld,
+                       t->rows, t->rowbuf, t->colbuf, t->state, check_status, serpentine);
+}
+
+// variant: low byte selects the tile shape, bit 8 turns the serpentine sweep on.
+int num_update_variants() { return 8; }
+
+void launch_update(lpr_tableau* t, int variant, int check_status) {
+    const int serp = (variant >> 8) & 1;
+    switch (variant & 0xff) {
+        default:
+        case 0: launch_update_t<16, 1>(t, check_status, serp); break;
+        case 1: launch_update_t<8, 1>(t, check_status, serp); break;
+        case 2: launch_update_t<8, 2>(t, check_status, serp); break;
+        case 3: launch_update_t<4, 2>(t, check_status, serp); break;
+        case 4: launch_update_t<4, 4>(t, check_status, serp); break;
+        case 5: launch_update_t<32, 1>(t, check_status, serp); break;
+        case 6: launch_update_t<16, 2>(t, check_status, serp); break;
+        case 7: launch_update_t<2, 4>(t, check_status, serp); break;
+    }
+}
+
+void launch_extract(lpr_tableau* t, int n, double* x) {
+    hipLaunchKernelGGL(k_extract, dim3((n + 255) / 256), dim3(256), 0, t->eng->stream, t->T,
+                       t->ld, t->rows, t->cols, n, x);
+}
+
+void launch_build(lpr_tableau* t, int n, int m, const double* d_obj, const double* d_A, int lda,
+                  const int32_t* d_ncoef, const int8_t* d_rel, const double* d_rhs, int is_max) {
+    hipStream_t s = t->eng->stream;
+    if (n > 0)
+        hipLaunchKernelGGL(k_build_obj, dim3((n + 255) / 256), dim3(256), 0, s, t->T, n, d_obj,
+                           is_max);
+    if (m > 0) {
+        const int nx = n > 0 ? (n + 255) / 256 : 1;
+        hipLaunchKernelGGL(k_build_rows, dim3(nx, m), dim3(256), 0, s, t->T, t->ld, n, m, d_A,
+                           lda, d_ncoef, d_rel, d_rhs, t->basis);
+    }
+}
+
+void launch_synthetic(lpr_tableau* t, int m, int n, uint64_t seed) {
+    hipLaunchKernelGGL(k_synthetic, dim3((t->ld + 255) / 256, t->rows), dim3(256), 0,
+                       t->eng->stream, t->T, t->ld, m, n, seed, t->basis);
+}
+
+}  // namespace lpr

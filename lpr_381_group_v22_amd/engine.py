@@ -1,0 +1,182 @@
+"""Handle wrappers over the C ABI (include/lpr_engine.h): Engine and device-resident Tableau."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _native as N
+
+
+def _dptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _i32ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+class Engine:
+    """One HIP device + one stream (lpr_engine_open / lpr_engine_close)."""
+
+    def __init__(self, device: int = 0):
+        h = C.c_void_p()
+        N.check(N.lib.lpr_engine_open(device, C.byref(h)), "lpr_engine_open")
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if self._h:
+            N.lib.lpr_engine_close(self._h)
+            self._h = None
+
+    def sync(self):
+        N.check(N.lib.lpr_engine_sync(self._h), "lpr_engine_sync")
+
+    @property
+    def stream(self) -> int:
+        return int(N.lib.lpr_engine_stream(self._h))
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_engine: Optional[Engine] = None
+
+
+def default_engine() -> Engine:
+    global _default_engine
+    if _default_engine is None or _default_engine._h is None:
+        _default_engine = Engine(0)
+    return _default_engine
+
+
+class Tableau:
+    """A (rows x cols) fp64 simplex tableau resident in HBM (lpr_tableau_*)."""
+
+    def __init__(self, engine: Engine, handle: C.c_void_p):
+        self.engine = engine
+        self._h = handle
+        r, c, ld = C.c_int(), C.c_int(), C.c_int()
+        N.check(N.lib.lpr_tableau_shape(handle, C.byref(r), C.byref(c), C.byref(ld)),
+                "lpr_tableau_shape")
+        self.rows, self.cols, self.ld = r.value, c.value, ld.value
+
+    # ---- constructors -------------------------------------------------------------------
+    @classmethod
+    def from_lp(cls, engine: Engine, objective: Sequence[float], A: np.ndarray,
+                relation: Sequence[int], rhs: Sequence[float], is_max: bool = True,
+                ncoef: Optional[Sequence[int]] = None) -> "Tableau":
+        obj = np.ascontiguousarray(objective, dtype=np.float64)
+        n = obj.shape[0]
+        rhs_a = np.ascontiguousarray(rhs, dtype=np.float64)
+        m = rhs_a.shape[0]
+        A = np.ascontiguousarray(A, dtype=np.float64).reshape(m, -1) if m else np.zeros((0, n))
+        lda = A.shape[1] if m else n
+        rel = np.ascontiguousarray(relation, dtype=np.int8)
+        nc = None if ncoef is None else np.ascontiguousarray(ncoef, dtype=np.int32)
+        h = C.c_void_p()
+        N.check(N.lib.lpr_tableau_from_lp(
+            engine._h, n, m, _dptr(obj), _dptr(A) if m and lda else None, lda,
+            _i32ptr(nc), rel.ctypes.data_as(C.POINTER(C.c_int8)) if m else None,
+            _dptr(rhs_a) if m else None, 1 if is_max else 0, C.byref(h)), "lpr_tableau_from_lp")
+        return cls(engine, h)
+
+    @classmethod
+    def from_array(cls, engine: Engine, T: np.ndarray,
+                   basis: Optional[Sequence[int]] = None) -> "Tableau":
+        T = np.ascontiguousarray(T, dtype=np.float64)
+        b = None if basis is None else np.ascontiguousarray(basis, dtype=np.int32)
+        h = C.c_void_p()
+        N.check(N.lib.lpr_tableau_create(engine._h, T.shape[0], T.shape[1], _dptr(T),
+                                         _i32ptr(b), C.byref(h)), "lpr_tableau_create")
+        return cls(engine, h)
+
+    @classmethod
+    def synthetic(cls, engine: Engine, m: int, n: int, seed: int) -> "Tableau":
+        h = C.c_void_p()
+        N.check(N.lib.lpr_tableau_synthetic(engine._h, m, n, C.c_uint64(seed), C.byref(h)),
+                "lpr_tableau_synthetic")
+        return cls(engine, h)
+
+    def destroy(self):
+        if self._h:
+            N.lib.lpr_tableau_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+    # ---- the pivot loop -----------------------------------------------------------------
+    def solve(self, max_pivots: int = 0, time_kernels: bool = False, batch: int = 0,
+              variant: int = 0) -> N.SolveResult:
+        opts = N.SolveOpts(max_pivots=max_pivots, time_kernels=1 if time_kernels else 0,
+                           batch=batch, variant=variant, reserved=0)
+        res = N.SolveResult()
+        N.check(N.lib.lpr_primal_solve(self._h, C.byref(opts), C.byref(res)), "lpr_primal_solve")
+        return res
+
+    def select_entering(self) -> int:
+        v = C.c_int32()
+        N.check(N.lib.lpr_select_entering(self._h, C.byref(v)), "lpr_select_entering")
+        return v.value
+
+    def select_leaving(self, col: int) -> int:
+        v = C.c_int32()
+        N.check(N.lib.lpr_select_leaving(self._h, col, C.byref(v)), "lpr_select_leaving")
+        return v.value
+
+    def pivot(self, row: int, col: int) -> None:
+        N.check(N.lib.lpr_pivot(self._h, row, col), "lpr_pivot")
+
+    # ---- results ------------------------------------------------------------------------
+    def extract_solution(self, n: int) -> Tuple[np.ndarray, float]:
+        x = np.zeros(max(n, 1), dtype=np.float64)
+        z = C.c_double()
+        N.check(N.lib.lpr_extract_solution(self._h, n, _dptr(x), C.byref(z)),
+                "lpr_extract_solution")
+        return x[:n], z.value
+
+    def read(self) -> np.ndarray:
+        out = np.empty((self.rows, self.cols), dtype=np.float64)
+        N.check(N.lib.lpr_tableau_read(self._h, _dptr(out)), "lpr_tableau_read")
+        return out
+
+    def read_block(self, row0: int, nrows: int, col0: int, ncols: int) -> np.ndarray:
+        out = np.empty((nrows, ncols), dtype=np.float64)
+        N.check(N.lib.lpr_tableau_read_block(self._h, row0, nrows, col0, ncols, _dptr(out)),
+                "lpr_tableau_read_block")
+        return out
+
+    def basis(self) -> np.ndarray:
+        out = np.zeros(max(self.rows - 1, 1), dtype=np.int32)
+        N.check(N.lib.lpr_basis_read(self._h, _i32ptr(out)), "lpr_basis_read")
+        return out[: self.rows - 1]
+
+    def pivot_log(self, cap: int = 1 << 20) -> np.ndarray:
+        rows = np.zeros(cap, dtype=np.int32)
+        cols = np.zeros(cap, dtype=np.int32)
+        cnt = C.c_int64()
+        N.check(N.lib.lpr_pivot_log_read(self._h, _i32ptr(rows), _i32ptr(cols), cap,
+                                         C.byref(cnt)), "lpr_pivot_log_read")
+        k = cnt.value
+        return np.stack([rows[:k], cols[:k]], axis=1)
+
+    def kernel_stats(self) -> Tuple[int, float, float]:
+        n, tot, avg = C.c_int64(), C.c_double(), C.c_double()
+        N.check(N.lib.lpr_tableau_kernel_stats(self._h, C.byref(n), C.byref(tot), C.byref(avg)),
+                "lpr_tableau_kernel_stats")
+        return n.value, tot.value, avg.value

@@ -1,0 +1,65 @@
+/*
+ * lpr_oracle.h -- CPU restatement of the reference's dense-tableau simplex path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under lpr_381_group_v22_amd/ or include/ may include, link,
+ * import or execute anything in this directory; only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg do, and there only as the checker / the CPU timing baseline.
+ *
+ * PARITY UNPINNED BY THE REFERENCE: Storm-Tarran/LPR_381_Group_V22 ships no tests, no golden
+ * outputs (data/output_results.txt is 0 bytes) and cannot be compiled here (C# / .NET Framework
+ * 4.7.2, no toolchain in the image; the project also references types that do not exist,
+ * Program.cs:444,468).  What pins this oracle instead: (1) it is a literal, loop-for-loop
+ * restatement of the cited C# lines, compiled with -ffp-contract=off and no fast-math; (2) an
+ * independently written Python restatement (tests/ref_py.py) must agree with it bit-for-bit on
+ * pivot logs, bases and result bits; (3) the hand-traced results in SURVEY.md section 4;
+ * (4) scipy.optimize.linprog objective values on well-posed LPs.
+ *
+ * Floating point model: IEEE binary64, round-to-nearest-even, every C# operator one rounding
+ * (x64 RyuJIT / SSE2 semantics; an x87 32-bit JIT could differ -- DESIGN.md).
+ */
+#ifndef LPR_ORACLE_H
+#define LPR_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* same numeric values as include/lpr_engine.h (tests assert this) */
+enum {
+    ORC_OK_OPTIMAL = 0,
+    ORC_UNBOUNDED = 1,
+    ORC_INFEASIBLE_BASIS = 2,
+    ORC_PIVOT_TOO_SMALL = 3,
+    ORC_ENTERING_ALREADY_BASIC = 4,
+    ORC_PIVOT_LIMIT = 5,
+    ORC_BB_NODE_CAP = 6,
+    ORC_BAD_ARGUMENT = -1
+};
+
+/* ---- synthetic LP generator (spec in DESIGN.md; the device implements the same function) ---- */
+uint64_t orc_splitmix64(uint64_t x);
+double orc_u01(uint64_t seed, uint64_t stream, uint64_t i, uint64_t j);
+/* c[n], A[m*n] row-major, b[m] */
+void orc_gen_dense_lp(int m, int n, uint64_t seed, double* c, double* A, double* b);
+/* the (m+1) x (n+m+1) tableau of that LP, built directly (for the CPU baseline at full size) */
+void orc_gen_dense_tableau(int m, int n, uint64_t seed, double* T, int32_t* basis);
+
+/* ---- PrimalSimplexSolver (Simplex/PrimalSimplexSolver.cs) ---- */
+/* ctor :27-87.  T is (m+1) x (n+m+1) row-major, basis has m entries. */
+int orc_primal_build(int n, int m, const double* objective, const double* A, int lda,
+                     const int32_t* ncoef, const int8_t* relation, const double* rhs, int is_max,
+                     double* T, int32_t* basis);
+int orc_find_entering(const double* T, int R, int C);          /* :152-167 */
+int orc_find_leaving(const double* T, int R, int C, int e);    /* :169-191 */
+void orc_pivot(double* T, int R, int C, int r, int e);         /* :193-211 */
+/* Solve :102-150.  log_rows/log_cols may be NULL.  Returns status. */
+int orc_primal_solve(double* T, int R, int C, int32_t* basis, int64_t max_pivots,
+                     int32_t* log_rows, int32_t* log_cols, int64_t log_cap, int64_t* pivots);
+void orc_extract_solution(const double* T, int R, int C, int n, double* x, double* z); /* :213-252 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

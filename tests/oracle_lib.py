@@ -1,0 +1,126 @@
+"""ctypes binding of oracle/_build/liblpr_oracle.so (TEST ONLY -- the checker, never the product)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional, Tuple
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "_build", "liblpr_oracle.so")
+
+_D = C.POINTER(C.c_double)
+_I32 = C.POINTER(C.c_int32)
+_I8 = C.POINTER(C.c_int8)
+_I64 = C.POINTER(C.c_int64)
+
+
+def _newest_src() -> float:
+    return max(os.path.getmtime(os.path.join(ORACLE_DIR, f)) for f in os.listdir(ORACLE_DIR)
+               if f.endswith((".c", ".h")) or f == "Makefile")
+
+
+def build_oracle() -> str:
+    if not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < _newest_src():
+        subprocess.run(["make", "-C", ORACLE_DIR], check=True, capture_output=True)
+    return ORACLE_SO
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(_D)
+
+
+def _ip(a):
+    return None if a is None else a.ctypes.data_as(_I32)
+
+
+class Oracle:
+    def __init__(self):
+        self.lib = lib = C.CDLL(build_oracle())
+        lib.orc_splitmix64.restype = C.c_uint64
+        lib.orc_splitmix64.argtypes = [C.c_uint64]
+        lib.orc_u01.restype = C.c_double
+        lib.orc_u01.argtypes = [C.c_uint64] * 4
+        lib.orc_gen_dense_lp.restype = None
+        lib.orc_gen_dense_lp.argtypes = [C.c_int, C.c_int, C.c_uint64, _D, _D, _D]
+        lib.orc_gen_dense_tableau.restype = None
+        lib.orc_gen_dense_tableau.argtypes = [C.c_int, C.c_int, C.c_uint64, _D, _I32]
+        lib.orc_primal_build.restype = C.c_int
+        lib.orc_primal_build.argtypes = [C.c_int, C.c_int, _D, _D, C.c_int, _I32, _I8, _D,
+                                         C.c_int, _D, _I32]
+        lib.orc_find_entering.restype = C.c_int
+        lib.orc_find_entering.argtypes = [_D, C.c_int, C.c_int]
+        lib.orc_find_leaving.restype = C.c_int
+        lib.orc_find_leaving.argtypes = [_D, C.c_int, C.c_int, C.c_int]
+        lib.orc_pivot.restype = None
+        lib.orc_pivot.argtypes = [_D, C.c_int, C.c_int, C.c_int, C.c_int]
+        lib.orc_primal_solve.restype = C.c_int
+        lib.orc_primal_solve.argtypes = [_D, C.c_int, C.c_int, _I32, C.c_int64, _I32, _I32,
+                                         C.c_int64, _I64]
+        lib.orc_extract_solution.restype = None
+        lib.orc_extract_solution.argtypes = [_D, C.c_int, C.c_int, C.c_int, _D, _D]
+
+    # ---- generator ----
+    def u01(self, seed, stream, i, j) -> float:
+        return self.lib.orc_u01(seed, stream, i, j)
+
+    def gen_dense_lp(self, m: int, n: int, seed: int):
+        c = np.zeros(n)
+        A = np.zeros((m, n))
+        b = np.zeros(m)
+        self.lib.orc_gen_dense_lp(m, n, seed, _dp(c), _dp(A), _dp(b))
+        return c, A, b
+
+    def gen_dense_tableau(self, m: int, n: int, seed: int):
+        T = np.zeros((m + 1, n + m + 1))
+        basis = np.zeros(m, dtype=np.int32)
+        self.lib.orc_gen_dense_tableau(m, n, seed, _dp(T), _ip(basis))
+        return T, basis
+
+    # ---- primal ----
+    def primal_build(self, objective, A, relation, rhs, is_max=True, ncoef=None):
+        obj = np.ascontiguousarray(objective, dtype=np.float64)
+        n = obj.shape[0]
+        rhs = np.ascontiguousarray(rhs, dtype=np.float64)
+        m = rhs.shape[0]
+        A = np.ascontiguousarray(A, dtype=np.float64).reshape(m, -1) if m else np.zeros((0, n))
+        lda = A.shape[1] if m else n
+        rel = np.ascontiguousarray(relation, dtype=np.int8)
+        nc = None if ncoef is None else np.ascontiguousarray(ncoef, dtype=np.int32)
+        T = np.zeros((m + 1, n + m + 1))
+        basis = np.zeros(max(m, 1), dtype=np.int32)
+        rc = self.lib.orc_primal_build(n, m, _dp(obj), _dp(A), lda, _ip(nc),
+                                       rel.ctypes.data_as(_I8), _dp(rhs), 1 if is_max else 0,
+                                       _dp(T), _ip(basis))
+        assert rc == 0
+        return T, basis[:m]
+
+    def find_entering(self, T) -> int:
+        return self.lib.orc_find_entering(_dp(T), T.shape[0], T.shape[1])
+
+    def find_leaving(self, T, e) -> int:
+        return self.lib.orc_find_leaving(_dp(T), T.shape[0], T.shape[1], e)
+
+    def pivot(self, T, r, e) -> None:
+        self.lib.orc_pivot(_dp(T), T.shape[0], T.shape[1], r, e)
+
+    def primal_solve(self, T, basis: Optional[np.ndarray] = None, max_pivots: int = 0,
+                     log_cap: int = 1 << 16) -> Tuple[int, int, np.ndarray]:
+        """In place on T (and basis).  Returns (status, pivots, log[(row, col)])."""
+        assert T.flags["C_CONTIGUOUS"] and T.dtype == np.float64
+        lr = np.zeros(log_cap, dtype=np.int32)
+        lc = np.zeros(log_cap, dtype=np.int32)
+        piv = C.c_int64()
+        st = self.lib.orc_primal_solve(_dp(T), T.shape[0], T.shape[1], _ip(basis), max_pivots,
+                                       _ip(lr), _ip(lc), log_cap, C.byref(piv))
+        k = min(piv.value, log_cap)
+        return st, piv.value, np.stack([lr[:k], lc[:k]], axis=1)
+
+    def extract_solution(self, T, n):
+        x = np.zeros(max(n, 1))
+        z = C.c_double()
+        self.lib.orc_extract_solution(_dp(T), T.shape[0], T.shape[1], n, _dp(x), C.byref(z))
+        return x[:n], z.value

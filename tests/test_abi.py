@@ -1,0 +1,96 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads without a GPU, exports every symbol
+that include/lpr_engine.h declares (and nothing is declared that the binding does not know), the
+status enum matches the oracle's, and the product never reaches into oracle/."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "lpr_engine.h")
+PKG = os.path.join(ROOT, "lpr_381_group_v22_amd")
+
+
+@pytest.fixture(scope="module")
+def native():
+    lib = os.path.join(PKG, "_lib", "liblpr_engine.so")
+    if not os.path.exists(lib):
+        import sys
+        sys.path.insert(0, ROOT)
+        import __graft_entry__ as g
+        g.build()
+    from lpr_381_group_v22_amd import _native
+    return _native
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(lpr_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree(native):
+    decl = declared_functions()
+    assert decl, "no declarations parsed"
+    assert sorted(native.SIGNATURES) == decl
+
+
+def test_library_exports_every_declared_symbol(native):
+    lib = ctypes.CDLL(native.LIB_PATH)
+    for name in declared_functions():
+        assert hasattr(lib, name), f"{name} not exported"
+    assert lib.lpr_abi_version() == 1
+
+
+def test_open_without_gpu_fails_loudly(native):
+    """No CPU fallback: on a box without a gfx950 device the engine refuses to open."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    h = ctypes.c_void_p()
+    rc = native.lib.lpr_engine_open(0, ctypes.byref(h))
+    assert rc == native.LPR_DEVICE_ERROR
+    assert b"no CPU fallback" in native.lib.lpr_last_error()
+
+
+def test_status_enum_matches_oracle(native):
+    text = open(os.path.join(ROOT, "oracle", "lpr_oracle.h")).read()
+    orc = dict(re.findall(r"ORC_([A-Z_]+)\s*=\s*(-?\d+)", text))
+    eng = dict(re.findall(r"LPR_([A-Z_]+)\s*=\s*(-?\d+)", open(HEADER).read()))
+    for k, v in orc.items():
+        assert eng[k] == v, k
+
+
+def test_product_does_not_touch_the_oracle():
+    """Nothing shipped may import / include / link / dlopen the oracle or any CPU solver."""
+    bad = []
+    for base, _, files in os.walk(PKG):
+        if "_obj" in base or "_lib" in base or "__pycache__" in base:
+            continue
+        for f in files:
+            if not f.endswith((".py", ".hip", ".hpp", ".h", ".cpp", "Makefile")):
+                continue
+            s = open(os.path.join(base, f), errors="replace").read()
+            if re.search(r"lpr_oracle|liblpr_oracle|oracle_lib|ref_py|from\s+oracle|import\s+oracle", s):
+                bad.append(os.path.join(base, f))
+    assert not bad, bad
+    ldd = subprocess.run(["ldd", os.path.join(PKG, "_lib", "liblpr_engine.so")],
+                         capture_output=True, text=True).stdout
+    assert "oracle" not in ldd
+
+
+def test_no_fma_in_pivot_kernels():
+    """The C# rounds the product before the subtraction (PrimalSimplexSolver.cs:208); a contracted
+    v_fma_f64 in the rank-1 update would change bits.  Check the gfx950 ISA of every k_update
+    instantiation (division expansions in k_select legitimately use FMAs)."""
+    csrc = os.path.join(PKG, "csrc")
+    subprocess.run(["make", "-C", csrc, "isa"], check=True, capture_output=True)
+    s = open(os.path.join(csrc, "_obj", "primal_kernels.s")).read()
+    bodies = re.findall(r"^(_ZN3lpr8k_update\w+):[^\n]*\n(.*?)\.Lfunc_end", s, flags=re.S | re.M)
+    assert len(bodies) >= 4
+    for name, body in bodies:
+        assert "v_fma_f64" not in body and "v_fmac_f64" not in body, name
+        assert "v_mul_f64" in body and "v_add_f64" in body, name
+        assert "global_load_dwordx4" in body and "global_store_dwordx4" in body, name

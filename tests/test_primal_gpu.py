@@ -1,0 +1,246 @@
+"""GPU parity tests of the primal-simplex hot path: the HIP engine, called through the C ABI,
+against the CPU oracle on the same inputs.  Bar: bit-exact tableau, identical pivot log / basis /
+status, bit-exact Z and x (the path is IEEE binary64 with no re-association)."""
+import hashlib
+import struct
+
+import numpy as np
+import pytest
+
+import lp_cases
+
+pytestmark = pytest.mark.gpu
+
+STATUS = {0: "optimal", 1: "unbounded", 5: "limit"}
+
+
+def bits(x):
+    return struct.pack(">d", float(x)).hex()
+
+
+def oracle_run(oracle, obj, cons, is_max, max_pivots=0):
+    o, A, ncoef, rel, rhs = lp_cases.flatten(obj, cons)
+    T, basis = oracle.primal_build(o, A, rel, rhs, is_max, ncoef)
+    T0 = T.copy()
+    st, piv, log = oracle.primal_solve(T, basis, max_pivots)
+    x, z = oracle.extract_solution(T, len(obj))
+    return dict(T0=T0, T=T, basis=basis, status=st, pivots=piv, log=log, x=x, z=z)
+
+
+def to_constraints(cons):
+    from lpr_381_group_v22_amd import Constraint
+    return [Constraint(list(c.Coefficients), c.Relation, c.RHS) for c in cons]
+
+
+@pytest.mark.parametrize("name,case", lp_cases.all_cases(), ids=[c[0] for c in lp_cases.all_cases()])
+def test_solver_mirror_matches_oracle(engine, oracle, name, case):
+    from lpr_381_group_v22_amd import PrimalSimplexSolver
+    obj, cons, is_max = case
+    ref = oracle_run(oracle, obj, cons, is_max, max_pivots=5000)
+    s = PrimalSimplexSolver(obj, to_constraints(cons), is_max, engine=engine, snapshots="none")
+    assert s.tableau.read().tobytes() == ref["T0"].tobytes(), "constructor (a-P0) differs"
+    s.Solve(max_pivots=5000)
+    assert s.Status == ref["status"]
+    assert s.PivotLog.tolist() == ref["log"].tolist()
+    assert s.BasicVariables == ref["basis"].tolist()
+    assert s.GetFinalTableau().tobytes() == ref["T"].tobytes(), "final tableau not bit-identical"
+    if ref["status"] == 0:
+        assert bits(s.FinalZ) == bits(ref["z"])
+        assert [bits(v) for v in s.SolutionVector] == [bits(v) for v in ref["x"]]
+        assert s.FinalTableau.tobytes() == ref["T"].tobytes()
+    elif ref["status"] == 1:  # PrimalSimplexSolver.cs:129-135: no throw, FinalZ stays 0, x null
+        assert s.FinalZ == 0.0 and s.SolutionVector is None and s.FinalTableau is not None
+
+
+def test_golden_fixture_on_gpu(engine):
+    import json
+    import os
+    from lpr_381_group_v22_amd import PrimalSimplexSolver
+    with open(os.path.join(os.path.dirname(__file__), "golden", "primal_golden.json")) as f:
+        gold = json.load(f)
+    cases = dict(lp_cases.all_cases())
+    for name, g in gold.items():
+        obj, cons, is_max = cases[name]
+        s = PrimalSimplexSolver(obj, to_constraints(cons), is_max, engine=engine,
+                                snapshots="none")
+        s.Solve(max_pivots=5000)
+        assert STATUS[s.Status] == g["status"], name
+        assert s.PivotLog.tolist() == g["log"], name
+        assert s.BasicVariables == g["basis"], name
+        T = s.GetFinalTableau()
+        assert bits(T[0, -1]) == g["z_bits"], name
+        assert hashlib.sha256(T.tobytes()).hexdigest() == g["tableau_sha256"], name
+        x, _ = s.tableau.extract_solution(len(obj))
+        assert [bits(v) for v in x] == g["x_bits"], name
+
+
+def test_single_step_entry_points(engine, oracle):
+    """lpr_select_entering / lpr_select_leaving / lpr_pivot == FindEnteringVariable /
+    FindLeavingVariable / Pivot, one call at a time, including the snapshot-"all" host loop."""
+    from lpr_381_group_v22_amd import Tableau
+    for case in (lp_cases.sample_option1(), lp_cases.tie_heavy(24, 30, 2),
+                 lp_cases.random_dense(16, 32, 1)):
+        obj, cons, is_max = case
+        o, A, ncoef, rel, rhs = lp_cases.flatten(obj, cons)
+        T, basis = oracle.primal_build(o, A, rel, rhs, is_max, ncoef)
+        tab = Tableau.from_array(engine, T, basis)
+        for _ in range(200):
+            e = oracle.find_entering(T)
+            assert tab.select_entering() == e
+            if e < 0:
+                break
+            r = oracle.find_leaving(T, e)
+            assert tab.select_leaving(e) == r
+            if r < 0:
+                break
+            oracle.pivot(T, r, e)
+            basis[r - 1] = e
+            tab.pivot(r, e)
+            assert tab.read().tobytes() == T.tobytes()
+            assert tab.basis().tolist() == basis.tolist()
+        tab.destroy()
+
+
+def test_snapshot_policy_all_equals_batched(engine):
+    from lpr_381_group_v22_amd import PrimalSimplexSolver
+    obj, cons, is_max = lp_cases.sample_option1()
+    a = PrimalSimplexSolver(obj, to_constraints(cons), is_max, engine=engine, snapshots="all")
+    b = PrimalSimplexSolver(obj, to_constraints(cons), is_max, engine=engine, snapshots="none")
+    a.Solve()
+    b.Solve()
+    assert a.GetFinalTableau().tobytes() == b.GetFinalTableau().tobytes()
+    assert a.PivotLog.tolist() == b.PivotLog.tolist() == [[5, 3], [7, 5], [3, 1], [4, 2], [1, 0],
+                                                           [1, 4]]
+    assert bits(a.FinalZ) == bits(15.4) and a.BasicVariables == [4, 7, 1, 2, 3, 11, 5]
+    # initial + one per pivot + final block (PrimalSimplexSolver.cs:86,148,119-122)
+    assert len(a.IterationSnapshots) == 1 + 6 + 1
+    assert "Iteration 6 - After pivot:" in a.IterationSnapshots[6]
+    assert "Z = 15.400000" in a.IterationSnapshots[-1]
+
+
+def test_synthetic_generator_matches_oracle(engine, oracle):
+    from lpr_381_group_v22_amd import Tableau
+    for (m, n, seed) in [(5, 8, 7), (64, 128, 0), (100, 37, 3)]:
+        T, basis = oracle.gen_dense_tableau(m, n, seed)
+        tab = Tableau.synthetic(engine, m, n, seed)
+        assert tab.read().tobytes() == T.tobytes()
+        assert tab.basis().tolist() == basis.tolist()
+        tab.destroy()
+
+
+def test_all_update_variants_and_paths_give_identical_bits(engine, oracle):
+    """Tile shape, serpentine sweep, graph replay vs eager+events: same bits, same log."""
+    from lpr_381_group_v22_amd import Tableau
+    m, n, seed = 200, 333, 11
+    T, basis = oracle.gen_dense_tableau(m, n, seed)
+    st, piv, log = oracle.primal_solve(T, basis, 120)
+    want = T.tobytes()
+    for variant in list(range(1, 9)) + [0x100 + v for v in range(1, 9)]:
+        for timed in (False, True):
+            tab = Tableau.synthetic(engine, m, n, seed)
+            res = tab.solve(max_pivots=120, variant=variant, time_kernels=timed, batch=32)
+            assert res.status == st and res.pivots == piv
+            assert tab.pivot_log().tolist() == log.tolist()
+            assert tab.read().tobytes() == want, (variant, timed)
+            if timed:
+                launches, total_ms, avg_ms = tab.kernel_stats()
+                assert launches == piv and total_ms > 0 and avg_ms > 0
+            tab.destroy()
+
+
+def test_resume_after_pivot_limit(engine, oracle):
+    from lpr_381_group_v22_amd import Tableau
+    m, n, seed = 48, 96, 2
+    T, basis = oracle.gen_dense_tableau(m, n, seed)
+    st, piv, log = oracle.primal_solve(T, basis)
+    tab = Tableau.synthetic(engine, m, n, seed)
+    total = 0
+    while True:
+        res = tab.solve(max_pivots=7, batch=3)
+        total += res.pivots
+        assert res.total_pivots == total
+        if res.status != 5:
+            break
+        assert res.pivots == 7
+    assert res.status == st and total == piv
+    assert tab.pivot_log().tolist() == log.tolist()
+    assert tab.read().tobytes() == T.tobytes()
+    tab.destroy()
+
+
+def test_config1_m512_n1024_full_solve(engine, oracle):
+    """BASELINE configs[1]: dense random LP m=512 n=1024, solved to optimality on both sides."""
+    from lpr_381_group_v22_amd import Tableau
+    m, n, seed = 512, 1024, 0
+    T, basis = oracle.gen_dense_tableau(m, n, seed)
+    st, piv, log = oracle.primal_solve(T, basis, 20000)
+    x_ref, z_ref = oracle.extract_solution(T, n)
+    tab = Tableau.synthetic(engine, m, n, seed)
+    res = tab.solve(max_pivots=20000)
+    assert res.status == st == 0 and res.pivots == piv
+    assert tab.pivot_log(1 << 16).tolist() == log.tolist()
+    assert tab.basis().tolist() == basis.tolist()
+    assert tab.read().tobytes() == T.tobytes()
+    x, z = tab.extract_solution(n)
+    assert x.tobytes() == x_ref.tobytes() and bits(z) == bits(z_ref)
+    tab.destroy()
+
+
+def test_north_star_size_first_pivots_and_invariants(engine, oracle):
+    """m=4096, n=8192 (4097 x 12289, 402.8 MB): the first pivots bit-for-bit against the oracle,
+    then size-independent properties of the tableau after a longer run."""
+    from lpr_381_group_v22_amd import Tableau
+    m, n, seed, K = 4096, 8192, 0, 4
+    T, basis = oracle.gen_dense_tableau(m, n, seed)
+    tab = Tableau.synthetic(engine, m, n, seed)
+    assert tab.read_block(0, 3, 0, n + m + 1).tobytes() == T[:3].tobytes()
+    assert tab.read_block(4000, 97, 8000, 4289).tobytes() == \
+        np.ascontiguousarray(T[4000:, 8000:]).tobytes()
+    st, piv, log = oracle.primal_solve(T, basis, K)
+    res = tab.solve(max_pivots=K)
+    assert res.status == st == 5 and res.pivots == K
+    assert tab.pivot_log().tolist() == log.tolist()
+    got = tab.read()
+    assert hashlib.sha256(got.tobytes()).hexdigest() == hashlib.sha256(T.tobytes()).hexdigest()
+    del got, T
+    # longer run: invariants that hold for any correct Gauss-Jordan pivot sequence
+    z_prev = res.z
+    res = tab.solve(max_pivots=60)
+    assert res.pivots == 60 and res.z >= z_prev
+    b = tab.basis()
+    R, C = tab.rows, tab.cols
+    logk = tab.pivot_log()
+    r_last, e_last = logk[-1]
+    col = tab.read_block(0, R, int(e_last), 1)[:, 0]
+    unit = np.zeros(R)
+    unit[r_last] = 1.0
+    assert col.tobytes() == unit.tobytes(), "pivot column must be exactly e_r after the pivot"
+    assert b[r_last - 1] == e_last
+    rhs = tab.read_block(1, R - 1, C - 1, 1)[:, 0]
+    assert (rhs >= 0).all(), "ratio test keeps the basis primal feasible"
+    # every structural basic column is (numerically) a unit column, slack ones exactly identity
+    for row in (1, R // 2, R - 1):
+        cidx = int(b[row - 1])
+        colv = tab.read_block(0, R, cidx, 1)[:, 0]
+        assert abs(colv[row] - 1.0) < 1e-6 and np.abs(np.delete(colv, row)).max() < 1e-6
+    tab.destroy()
+
+
+def test_edge_shapes(engine, oracle):
+    from lpr_381_group_v22_amd import Constraint, PrimalSimplexSolver
+    # no constraints at all: R = 1; a positive objective is unbounded, a non-positive one optimal
+    s = PrimalSimplexSolver([1.0, 2.0], [], True, engine=engine, snapshots="none")
+    s.Solve()
+    assert s.Status == 1 and s.SolutionVector is None
+    s = PrimalSimplexSolver([-1.0, 0.0], [], True, engine=engine, snapshots="none")
+    s.Solve()
+    assert s.Status == 0 and s.FinalZ == 0.0 and s.SolutionVector == [0.0, 0.0]
+    # a single variable, a single row
+    s = PrimalSimplexSolver([3.0], [Constraint([2.0], "<=", 5.0)], True, engine=engine)
+    s.Solve()
+    assert s.Status == 0 and s.FinalZ == 7.5 and s.SolutionVector == [2.5]
+    assert s.PivotLog.tolist() == [[1, 0]] and s.BasicVariables == [0]
+    # minimisation keeps +c in the Z row (PrimalSimplexSolver.cs:62): nothing negative -> optimal
+    s = PrimalSimplexSolver([3.0, 1.0], [Constraint([1.0, 1.0], "<=", 2.0)], False, engine=engine)
+    s.Solve()
+    assert s.Status == 0 and s.PivotLog.shape[0] == 0 and s.FinalZ == 0.0
