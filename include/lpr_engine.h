@@ -101,7 +101,7 @@ int lpr_tableau_create(lpr_engine* e, int rows, int cols, const double* rowmajor
 /* Benchmark input: dense random LP generated ON the device by the counter-based
  * generator documented in DESIGN.md (SplitMix64 keyed by (seed, stream, i, j)), so that the
  * 402.8 MB tableau of the m=4096,n=8192 configuration never crosses PCIe:
- *   A[i][j] ~ U(0,1), b_i = 1 + U(0,1)*n/4, c_j ~ U(0,1), all "<=", maximise. */
+ *   A[i][j] ~ U(0,1), b_i = (n/4)*(1 + 0.1*U(0,1)), c_j ~ U(0,1), all "<=", maximise. */
 int lpr_tableau_synthetic(lpr_engine* e, int m, int n, uint64_t seed, lpr_tableau** out);
 
 int lpr_tableau_destroy(lpr_tableau* t);

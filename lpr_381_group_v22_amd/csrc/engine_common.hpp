@@ -54,11 +54,16 @@ struct PivotState {
 
 }  // namespace lpr
 
+struct lpr_tableau;
+
 struct lpr_engine {
     int device = 0;
     hipStream_t stream = nullptr;
     int num_cus = 0;
     char arch[64] = {0};
+    // tableaux created on this engine and not yet destroyed; lpr_engine_close releases their
+    // device memory and orphans them so that a late lpr_tableau_destroy stays safe
+    std::vector<lpr_tableau*> live;
 };
 
 struct lpr_tableau {

@@ -72,6 +72,7 @@ static int alloc_tableau(lpr_engine* e, int rows, int cols, lpr_tableau** out) {
                            e->stream));
     LPR_HIP(hipMemsetAsync(t->T, 0, tbytes, e->stream));
     LPR_HIP(hipMemsetAsync(t->rowbuf, 0, (size_t)t->ld * sizeof(double), e->stream));
+    e->live.push_back(t);
     *out = t;
     return LPR_OK_OPTIMAL;
 }
@@ -83,6 +84,28 @@ static void drop_graph(lpr_tableau* t) {
     }
     t->graph_batch = 0;
     t->graph_variant = -1;
+}
+
+// Frees everything the tableau holds on the device (the engine must still be alive).
+static void release_device(lpr_tableau* t) {
+    hipSetDevice(t->eng->device);
+    if (t->eng->stream) hipStreamSynchronize(t->eng->stream);
+    drop_graph(t);
+    for (hipEvent_t ev : t->ev) hipEventDestroy(ev);
+    t->ev.clear();
+    hipFree(t->T);
+    hipFree(t->rowbuf);
+    hipFree(t->colbuf);
+    hipFree(t->basis);
+    hipFree(t->log);
+    hipFree(t->state);
+    hipFree(t->scratch_i);
+    hipFree(t->xbuf);
+    if (t->h_state) hipHostFree(t->h_state);
+    if (t->h_scratch_i) hipHostFree(t->h_scratch_i);
+    t->T = t->rowbuf = t->colbuf = t->xbuf = nullptr;
+    t->basis = t->log = t->scratch_i = t->h_scratch_i = nullptr;
+    t->state = t->h_state = nullptr;
 }
 
 // Grow the pivot log so that `need` pairs fit (keeps the old entries).
@@ -120,6 +143,14 @@ static int default_batch(const lpr_tableau* t) {
 }  // namespace lpr
 
 using namespace lpr;
+
+#define LPR_LIVE(t)                                                              \
+    do {                                                                         \
+        if (!(t) || !(t)->eng) {                                                 \
+            set_error("tableau handle is null or its engine has been closed");   \
+            return LPR_BAD_ARGUMENT;                                             \
+        }                                                                        \
+    } while (0)
 
 extern "C" {
 
@@ -167,6 +198,11 @@ int lpr_engine_open(int device, lpr_engine** out) {
 int lpr_engine_close(lpr_engine* e) {
     if (!e) return LPR_BAD_ARGUMENT;
     hipSetDevice(e->device);
+    for (lpr_tableau* t : e->live) {  // orphan what the caller forgot to destroy
+        release_device(t);
+        t->eng = nullptr;
+    }
+    e->live.clear();
     if (e->stream) {
         hipStreamSynchronize(e->stream);
         hipStreamDestroy(e->stream);
@@ -302,22 +338,15 @@ int lpr_tableau_synthetic(lpr_engine* e, int m, int n, uint64_t seed, lpr_tablea
 
 int lpr_tableau_destroy(lpr_tableau* t) {
     if (!t) return LPR_BAD_ARGUMENT;
-    if (t->eng) {
-        hipSetDevice(t->eng->device);
-        if (t->eng->stream) hipStreamSynchronize(t->eng->stream);
+    if (t->eng) {  // still attached: release device memory, detach from the engine
+        release_device(t);
+        auto& lv = t->eng->live;
+        for (size_t k = 0; k < lv.size(); ++k)
+            if (lv[k] == t) {
+                lv.erase(lv.begin() + k);
+                break;
+            }
     }
-    drop_graph(t);
-    for (hipEvent_t ev : t->ev) hipEventDestroy(ev);
-    hipFree(t->T);
-    hipFree(t->rowbuf);
-    hipFree(t->colbuf);
-    hipFree(t->basis);
-    hipFree(t->log);
-    hipFree(t->state);
-    hipFree(t->scratch_i);
-    hipFree(t->xbuf);
-    if (t->h_state) hipHostFree(t->h_state);
-    if (t->h_scratch_i) hipHostFree(t->h_scratch_i);
     delete t;
     return LPR_OK_OPTIMAL;
 }
@@ -333,6 +362,7 @@ int lpr_tableau_shape(const lpr_tableau* t, int* rows, int* cols, int* ld) {
 // ------------------------------------------------------------------------------ solve
 
 int lpr_primal_solve(lpr_tableau* t, const lpr_solve_opts* opts, lpr_solve_result* res) {
+    LPR_LIVE(t);
     if (!t || !res) {
         set_error("lpr_primal_solve: null argument");
         return LPR_BAD_ARGUMENT;
@@ -455,6 +485,7 @@ static int read_scratch(lpr_tableau* t, int idx, int32_t* out) {
 }
 
 int lpr_select_entering(lpr_tableau* t, int32_t* col) {
+    LPR_LIVE(t);
     if (!t || !col) return LPR_BAD_ARGUMENT;
     LPR_HIP(hipSetDevice(t->eng->device));
     launch_select(t, kSelEnter, -1, -1, t->scratch_i);
@@ -462,6 +493,7 @@ int lpr_select_entering(lpr_tableau* t, int32_t* col) {
 }
 
 int lpr_select_leaving(lpr_tableau* t, int32_t col, int32_t* row) {
+    LPR_LIVE(t);
     if (!t || !row || col < 0 || col >= t->cols - 1) {
         set_error("lpr_select_leaving: column %d out of range", col);
         return LPR_BAD_ARGUMENT;
@@ -472,6 +504,7 @@ int lpr_select_leaving(lpr_tableau* t, int32_t col, int32_t* row) {
 }
 
 int lpr_pivot(lpr_tableau* t, int32_t row, int32_t col) {
+    LPR_LIVE(t);
     if (!t || row < 1 || row >= t->rows || col < 0 || col >= t->cols) {
         set_error("lpr_pivot: (%d, %d) out of range", row, col);
         return LPR_BAD_ARGUMENT;
@@ -495,6 +528,7 @@ int lpr_pivot(lpr_tableau* t, int32_t row, int32_t col) {
 }
 
 int lpr_extract_solution(lpr_tableau* t, int n, double* x, double* z) {
+    LPR_LIVE(t);
     if (!t || n < 0 || n > t->cols - 1 || (n > 0 && !x)) {
         set_error("lpr_extract_solution: bad arguments (n=%d)", n);
         return LPR_BAD_ARGUMENT;
@@ -522,6 +556,7 @@ int lpr_extract_solution(lpr_tableau* t, int n, double* x, double* z) {
 
 int lpr_tableau_read_block(lpr_tableau* t, int row0, int nrows, int col0, int ncols,
                            double* out) {
+    LPR_LIVE(t);
     if (!t || !out || row0 < 0 || col0 < 0 || nrows < 0 || ncols < 0 ||
         row0 + nrows > t->rows || col0 + ncols > t->cols) {
         set_error("lpr_tableau_read_block: block out of range");
@@ -538,11 +573,13 @@ int lpr_tableau_read_block(lpr_tableau* t, int row0, int nrows, int col0, int nc
 }
 
 int lpr_tableau_read(lpr_tableau* t, double* rowmajor_out) {
+    LPR_LIVE(t);
     if (!t) return LPR_BAD_ARGUMENT;
     return lpr_tableau_read_block(t, 0, t->rows, 0, t->cols, rowmajor_out);
 }
 
 int lpr_basis_read(lpr_tableau* t, int32_t* basis_out) {
+    LPR_LIVE(t);
     if (!t || !basis_out) return LPR_BAD_ARGUMENT;
     if (t->rows <= 1) return LPR_OK_OPTIMAL;
     LPR_HIP(hipSetDevice(t->eng->device));
@@ -555,6 +592,7 @@ int lpr_basis_read(lpr_tableau* t, int32_t* basis_out) {
 
 int lpr_pivot_log_read(lpr_tableau* t, int32_t* rows_out, int32_t* cols_out, int64_t cap,
                        int64_t* count) {
+    LPR_LIVE(t);
     if (!t || !count || cap < 0) return LPR_BAD_ARGUMENT;
     int64_t n = t->total_pivots < t->log_cap ? t->total_pivots : t->log_cap;
     if (n > cap) n = cap;
@@ -573,6 +611,7 @@ int lpr_pivot_log_read(lpr_tableau* t, int32_t* rows_out, int32_t* cols_out, int
 
 int lpr_tableau_kernel_stats(lpr_tableau* t, int64_t* launches, double* total_ms,
                              double* avg_ms) {
+    LPR_LIVE(t);
     if (!t) return LPR_BAD_ARGUMENT;
     if (launches) *launches = t->timed_launches;
     if (total_ms) *total_ms = t->timed_total_ms;

@@ -343,8 +343,9 @@ __global__ __launch_bounds__(256) void k_synthetic(double* __restrict__ T, int l
         else if (j == n + ci) v = 1.0;
         else if (j == C - 1) {
             const double u = u01(seed, 1, (uint64_t)ci, 0);
-            const double s = u * ((double)n * 0.25);
-            v = 1.0 + s;
+            const double s = u * 0.1;
+            const double t = 1.0 + s;
+            v = ((double)n * 0.25) * t;  // b_i = (n/4) * (1 + 0.1 U)
         }
         if (j == 0) basis[ci] = n + ci;
     }

@@ -34,13 +34,21 @@ double orc_u01(uint64_t seed, uint64_t stream, uint64_t i, uint64_t j) {
     return (double)(k >> 11) * 0x1.0p-53;
 }
 
+/* b_i = (n/4) * (1 + 0.1 * U): right-hand sides of similar size, so that many constraints compete
+ * in the ratio test and the LP needs O(m) pivots (with b_i spread over [1, n/4] a handful of tight
+ * rows decide the optimum and the solve ends after ~15 pivots -- useless as a pivot benchmark). */
+static double orc_rhs(uint64_t seed, int i, int n) {
+    double u = orc_u01(seed, 1, (uint64_t)i, 0);
+    double s = u * 0.1;
+    double t = 1.0 + s;
+    return ((double)n * 0.25) * t;
+}
+
 void orc_gen_dense_lp(int m, int n, uint64_t seed, double* c, double* A, double* b) {
     for (int j = 0; j < n; j++) c[j] = orc_u01(seed, 2, 0, (uint64_t)j);
     for (int i = 0; i < m; i++) {
         for (int j = 0; j < n; j++) A[(size_t)i * n + j] = orc_u01(seed, 0, (uint64_t)i, (uint64_t)j);
-        double u = orc_u01(seed, 1, (uint64_t)i, 0);
-        double s = u * ((double)n * 0.25);
-        b[i] = 1.0 + s;
+        b[i] = orc_rhs(seed, i, n);
     }
 }
 
@@ -52,9 +60,7 @@ void orc_gen_dense_tableau(int m, int n, uint64_t seed, double* T, int32_t* basi
         double* row = T + (size_t)(i + 1) * C;
         for (int j = 0; j < n; j++) row[j] = orc_u01(seed, 0, (uint64_t)i, (uint64_t)j);
         row[n + i] = 1.0;
-        double u = orc_u01(seed, 1, (uint64_t)i, 0);
-        double s = u * ((double)n * 0.25);
-        row[C - 1] = 1.0 + s;
+        row[C - 1] = orc_rhs(seed, i, n);
         if (basis) basis[i] = n + i;
     }
 }

@@ -115,7 +115,7 @@ def test_generator_spec(oracle):
         assert oracle.u01(*args) == u01(*args)
     c, A, b = oracle.gen_dense_lp(5, 8, 7)
     assert A[3, 2] == u01(7, 0, 3, 2) and c[6] == u01(7, 2, 0, 6)
-    assert b[4] == 1.0 + u01(7, 1, 4, 0) * (8 * 0.25)
+    assert b[4] == (8 * 0.25) * (1.0 + u01(7, 1, 4, 0) * 0.1)
     T, basis = oracle.gen_dense_tableau(5, 8, 7)
     T2, basis2 = oracle.primal_build(c, A, np.zeros(5, dtype=np.int8), b, True)
     assert T.tobytes() == T2.tobytes() and basis.tolist() == basis2.tolist()
