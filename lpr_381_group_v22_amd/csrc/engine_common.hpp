@@ -50,6 +50,9 @@ struct PivotState {
     int64_t iter;       // pivots performed so far
     int64_t max_iter;   // stop when iter reaches this (<= 0: no limit)
     int64_t log_cap;    // capacity of the pivot log in pairs
+    int32_t next_e;     // entering column of the NEXT pivot, chosen by k_pivot_head from the Z row
+                        // it has just computed in registers (-1: the next tableau is optimal)
+    int32_t pad;
 };
 
 }  // namespace lpr
@@ -72,6 +75,8 @@ struct lpr_tableau {
     double* T = nullptr;             // rows x ld, row-major, padding columns kept at 0
     double* rowbuf = nullptr;        // ld doubles: normalised pivot row
     double* colbuf = nullptr;        // rows doubles: pivot column before the update
+    double* next_col = nullptr;      // rows doubles: column next_e of the tableau AFTER the update
+    double* next_rhs = nullptr;      // rows doubles: RHS column of the tableau AFTER the update
     int32_t* basis = nullptr;        // rows-1
     int32_t* log = nullptr;          // 2*log_cap: (row, col) pairs
     int64_t log_cap = 0;

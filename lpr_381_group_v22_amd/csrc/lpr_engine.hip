@@ -25,7 +25,9 @@ const char* get_error() { return g_err.c_str(); }
 
 // primal_kernels.hip
 void launch_select(lpr_tableau* t, int mode, int e_in, int r_in, int32_t* out_i);
-void launch_update(lpr_tableau* t, int variant, int check_status);
+void launch_bootstrap(lpr_tableau* t);
+void launch_pivot_head(lpr_tableau* t);
+void launch_update(lpr_tableau* t, int variant, int check_status, int dump_next);
 int num_update_variants();
 void launch_extract(lpr_tableau* t, int n, double* x);
 void launch_build(lpr_tableau* t, int n, int m, const double* d_obj, const double* d_A, int lda,
@@ -53,6 +55,8 @@ static int alloc_tableau(lpr_engine* e, int rows, int cols, lpr_tableau** out) {
     chk(hipMalloc(&t->T, tbytes));
     chk(hipMalloc(&t->rowbuf, (size_t)t->ld * sizeof(double)));
     chk(hipMalloc(&t->colbuf, (size_t)align_up(rows, 16) * sizeof(double)));
+    chk(hipMalloc(&t->next_col, (size_t)align_up(rows, 16) * sizeof(double)));
+    chk(hipMalloc(&t->next_rhs, (size_t)align_up(rows, 16) * sizeof(double)));
     chk(hipMalloc(&t->basis, (size_t)(rows > 1 ? rows - 1 : 1) * sizeof(int32_t)));
     chk(hipMalloc(&t->log, (size_t)t->log_cap * 2 * sizeof(int32_t)));
     chk(hipMalloc(&t->state, sizeof(PivotState)));
@@ -96,6 +100,8 @@ static void release_device(lpr_tableau* t) {
     hipFree(t->T);
     hipFree(t->rowbuf);
     hipFree(t->colbuf);
+    hipFree(t->next_col);
+    hipFree(t->next_rhs);
     hipFree(t->basis);
     hipFree(t->log);
     hipFree(t->state);
@@ -103,7 +109,7 @@ static void release_device(lpr_tableau* t) {
     hipFree(t->xbuf);
     if (t->h_state) hipHostFree(t->h_state);
     if (t->h_scratch_i) hipHostFree(t->h_scratch_i);
-    t->T = t->rowbuf = t->colbuf = t->xbuf = nullptr;
+    t->T = t->rowbuf = t->colbuf = t->xbuf = t->next_col = t->next_rhs = nullptr;
     t->basis = t->log = t->scratch_i = t->h_scratch_i = nullptr;
     t->state = t->h_state = nullptr;
 }
@@ -125,9 +131,18 @@ static int ensure_log(lpr_tableau* t, int64_t need) {
     return LPR_OK_OPTIMAL;
 }
 
+// Tile shape: the tallest row tile (more loads in flight per lane, pivot-row slice reused over
+// more rows) that still gives the 256 CUs >= 8 workgroups each; measured on the 4097 x 12289
+// tableau TR=32 is the fastest (profiles/).  The serpentine sweep (bit 8) reverses the tile order
+// on alternate pivots so the tail of one sweep is re-read from the 256 MiB Infinity Cache.
 static int default_variant(const lpr_tableau* t) {
-    (void)t;
-    return 0;
+    const long ctiles = (t->ld / 2 + 255) / 256;
+    struct { int tr; int idx; } opts[] = {{32, 5}, {16, 0}, {8, 1}, {4, 8}, {2, 9}, {1, 10}};
+    for (auto& o : opts) {
+        const long blocks = ctiles * ((t->rows + o.tr - 1) / o.tr);
+        if (blocks >= 2048 || o.tr == 1) return o.idx | 0x100;
+    }
+    return 0x100;
 }
 
 static int default_batch(const lpr_tableau* t) {
@@ -391,6 +406,10 @@ int lpr_primal_solve(lpr_tableau* t, const lpr_solve_opts* opts, lpr_solve_resul
     LPR_HIP(hipMemcpyAsync(&t->state->iter, &hs->iter, 3 * sizeof(int64_t),
                            hipMemcpyHostToDevice, s));
 
+    // One slow pass (strided column gather) primes next_e / next_col / next_rhs; from then on every
+    // k_update leaves them ready for the following k_pivot_head.
+    launch_bootstrap(t);
+
     int status = kRunning;
     int64_t iter = start_iter;
     while (status == kRunning) {
@@ -414,21 +433,21 @@ int lpr_primal_solve(lpr_tableau* t, const lpr_solve_opts* opts, lpr_solve_resul
                 t->ev.push_back(ev);
             }
             for (int k = 0; k < nb; ++k) {
-                launch_select(t, kSelFull, -1, -1, nullptr);
+                launch_pivot_head(t);
                 LPR_HIP(hipEventRecord(t->ev[2 * k], s));
-                launch_update(t, variant, 1);
+                launch_update(t, variant, 1, 1);
                 LPR_HIP(hipEventRecord(t->ev[2 * k + 1], s));
             }
             if (nb == 0 || (max_iter > 0 && iter + nb >= max_iter))
-                launch_select(t, kSelFull, -1, -1, nullptr);  // closing loop head -> final status
+                launch_pivot_head(t);  // closing loop head -> final status
         } else {
             if (!t->graph || t->graph_batch != nb || t->graph_variant != variant) {
                 drop_graph(t);
                 hipGraph_t g = nullptr;
                 LPR_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
                 for (int k = 0; k < nb; ++k) {
-                    launch_select(t, kSelFull, -1, -1, nullptr);
-                    launch_update(t, variant, 1);
+                    launch_pivot_head(t);
+                    launch_update(t, variant, 1, 1);
                 }
                 LPR_HIP(hipStreamEndCapture(s, &g));
                 hipError_t ierr = hipGraphInstantiate(&t->graph, g, nullptr, nullptr, 0);
@@ -520,7 +539,7 @@ int lpr_pivot(lpr_tableau* t, int32_t row, int32_t col) {
     LPR_HIP(hipMemcpyAsync(&t->state->iter, &hs->iter, 3 * sizeof(int64_t),
                            hipMemcpyHostToDevice, s));
     launch_select(t, kSelCommit, col, row, nullptr);
-    launch_update(t, default_variant(t), 0);
+    launch_update(t, default_variant(t), 0, 0);
     LPR_HIP(hipGetLastError());
     LPR_HIP(hipStreamSynchronize(s));
     t->total_pivots += 1;

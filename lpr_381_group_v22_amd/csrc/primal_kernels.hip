@@ -98,11 +98,20 @@ __global__ __launch_bounds__(1024) void k_select(double* __restrict__ T, int ld,
         Cand c;
         c.v = 0.0;  // mostNegative = 0
         c.i = -1;
-        for (int j = tid; j < C - 1; j += nt) {
-            double v = T[j];
-            if (v < c.v) {  // strict: ties keep the lower index, NaN and -0 never enter
-                c.v = v;
-                c.i = j;
+        // 4 independent loads in flight per lane; candidates are folded in ascending j
+        for (int j0 = tid; j0 < C - 1; j0 += 4 * nt) {
+            double v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * nt;
+                v[u] = (j < C - 1) ? T[j] : 0.0;  // 0.0 is never < mostNegative
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (v[u] < c.v) {  // strict: ties keep the lower index, NaN and -0 never enter
+                    c.v = v[u];
+                    c.i = j0 + u * nt;
+                }
             }
         }
         c = block_cand_min(c, lds_v, lds_i);
@@ -123,14 +132,27 @@ __global__ __launch_bounds__(1024) void k_select(double* __restrict__ T, int ld,
         c.v = DBL_MAX;  // double.MaxValue
         c.i = -1;
         const int rhs = C - 1;
-        for (int i = tid; i < R; i += nt) {
-            const double a = T[(size_t)i * ld + e];
-            colbuf[i] = a;
-            if (i >= 1 && a > 1e-9) {
-                const double ratio = T[(size_t)i * ld + rhs] / a;  // IEEE division
-                if (ratio >= 0 && ratio < c.v) {
-                    c.v = ratio;
-                    c.i = i;
+        for (int i0 = tid; i0 < R; i0 += 4 * nt) {
+            double a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {  // 8 strided loads in flight per lane
+                const int i = i0 + u * nt;
+                const bool in = i < R;
+                a[u] = in ? T[(size_t)i * ld + e] : 0.0;
+                b[u] = in ? T[(size_t)i * ld + rhs] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * nt;
+                if (i < R) {
+                    colbuf[i] = a[u];
+                    if (i >= 1 && a[u] > 1e-9) {
+                        const double ratio = b[u] / a[u];  // IEEE division
+                        if (ratio >= 0 && ratio < c.v) {
+                            c.v = ratio;
+                            c.i = i;
+                        }
+                    }
                 }
             }
         }
@@ -158,7 +180,19 @@ __global__ __launch_bounds__(1024) void k_select(double* __restrict__ T, int ld,
     // rowbuf[j] = T[r, j] / T[r, e] (true division).  The row itself is rewritten by k_update.
     const double p = T[(size_t)r * ld + e];
     const double* prow = T + (size_t)r * ld;
-    for (int j = tid; j < ld; j += nt) rowbuf[j] = (j < C) ? prow[j] / p : 0.0;
+    for (int j0 = tid; j0 < ld; j0 += 4 * nt) {
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + u * nt;
+            v[u] = (j < C) ? prow[j] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + u * nt;
+            if (j < ld) rowbuf[j] = (j < C) ? v[u] / p : 0.0;
+        }
+    }
     if (!gather_in_leave) {
         for (int i = tid; i < R; i += nt) colbuf[i] = T[(size_t)i * ld + e];
     }
@@ -178,6 +212,197 @@ __global__ __launch_bounds__(1024) void k_select(double* __restrict__ T, int ld,
 }
 
 // ------------------------------------------------------------------------------------------
+// k_bootstrap: primes the pipelined loop head.  FindEnteringVariable (:152-167) on the current Z
+// row -> st->next_e, and the strided gather of column next_e and of the RHS column into the dense
+// next_col / next_rhs vectors.  Runs once per lpr_primal_solve call; afterwards k_update keeps
+// those vectors current as a by-product of its sweep.
+__global__ __launch_bounds__(1024) void k_bootstrap(const double* __restrict__ T, int ld, int R,
+                                                    int C, double* __restrict__ next_col,
+                                                    double* __restrict__ next_rhs,
+                                                    PivotState* st) {
+    __shared__ double lds_v[16];
+    __shared__ int lds_i[16];
+    const int tid = threadIdx.x;
+    const int nt = blockDim.x;
+    Cand c;
+    c.v = 0.0;
+    c.i = -1;
+    for (int j0 = tid; j0 < C - 1; j0 += 4 * nt) {
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + u * nt;
+            v[u] = (j < C - 1) ? T[j] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (v[u] < c.v) {
+                c.v = v[u];
+                c.i = j0 + u * nt;
+            }
+        }
+    }
+    c = block_cand_min(c, lds_v, lds_i);
+    const int e = c.i;
+    if (tid == 0) st->next_e = e;
+    if (e < 0) return;
+    const int rhs = C - 1;
+    for (int i0 = tid; i0 < R; i0 += 4 * nt) {
+        double a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * nt;
+            const bool in = i < R;
+            a[u] = in ? T[(size_t)i * ld + e] : 0.0;
+            b[u] = in ? T[(size_t)i * ld + rhs] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * nt;
+            if (i < R) {
+                next_col[i] = a[u];
+                next_rhs[i] = b[u];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_pivot_head: one C# loop head (Solve :107-142) in two memory round trips.
+//   1. e = st->next_e, already chosen (-1 -> optimal, :110-126).
+//   2. FindLeavingVariable (:169-191) over the DENSE next_col / next_rhs vectors that the previous
+//      k_update wrote while it streamed the tableau (coalesced, no strided gather); next_col is
+//      also this pivot's factor column (colbuf).
+//   3. Pivot, first half (:195-199): rowbuf = T[r, :] / T[r, e]; at the same time the Z row of the
+//      tableau AFTER this pivot is formed in registers, z'[j] = T[0, j] - (f0 * rowbuf[j]) --
+//      the very expression k_update will store -- and FindEnteringVariable (:152-167) runs on it,
+//      so the NEXT entering column is known before this pivot's update starts and k_update can
+//      dump that column on the fly.
+// MAXC2 = double2 chunks per lane per trip (one trip covers 2048 * MAXC2 doubles of the row).
+template <int MAXC2>
+__global__ __launch_bounds__(1024) void k_pivot_head(const double* __restrict__ T, int ld, int R,
+                                                     int C, double* __restrict__ rowbuf,
+                                                     double* __restrict__ colbuf,
+                                                     const double* __restrict__ next_col,
+                                                     const double* __restrict__ next_rhs,
+                                                     int32_t* __restrict__ basis,
+                                                     int32_t* __restrict__ log, PivotState* st) {
+    __shared__ double lds_v[16];
+    __shared__ int lds_i[16];
+    const int tid = threadIdx.x;
+    const int nt = blockDim.x;
+
+    if (st->status != kRunning) return;
+    const int e = st->next_e;
+    if (e < 0) {
+        if (tid == 0) st->status = LPR_OK_OPTIMAL;
+        return;
+    }
+
+    // ---- FindLeavingVariable on the dense vectors ----
+    Cand c;
+    c.v = DBL_MAX;
+    c.i = -1;
+    for (int i0 = tid; i0 < R; i0 += 4 * nt) {
+        double a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * nt;
+            const bool in = i < R;
+            a[u] = in ? next_col[i] : 0.0;
+            b[u] = in ? next_rhs[i] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * nt;
+            if (i < R) {
+                colbuf[i] = a[u];
+                if (i >= 1 && a[u] > 1e-9) {
+                    const double ratio = b[u] / a[u];
+                    if (ratio >= 0 && ratio < c.v) {
+                        c.v = ratio;
+                        c.i = i;
+                    }
+                }
+            }
+        }
+    }
+    c = block_cand_min(c, lds_v, lds_i);
+    const int r = c.i;
+    if (r < 0) {
+        if (tid == 0) st->status = LPR_UNBOUNDED;
+        return;
+    }
+    {
+        const int64_t it = st->iter;
+        const int64_t mx = st->max_iter;
+        if (mx > 0 && it >= mx) {
+            if (tid == 0) st->status = LPR_PIVOT_LIMIT;
+            return;
+        }
+    }
+
+    // ---- normalise row r, form the next Z row, pick the next entering column ----
+    const double p = next_col[r];   // T[r, e]
+    const double f0 = next_col[0];  // T[0, e]
+    const int ld2 = ld >> 1;
+    const double2* __restrict__ prow2 = reinterpret_cast<const double2*>(T + (size_t)r * ld);
+    const double2* __restrict__ zrow2 = reinterpret_cast<const double2*>(T);
+    double2* __restrict__ out2 = reinterpret_cast<double2*>(rowbuf);
+    Cand n;
+    n.v = 0.0;
+    n.i = -1;
+    for (int base = 0; base < ld2; base += nt * MAXC2) {  // one trip when ld <= 2048 * MAXC2
+        double2 pv[MAXC2], zv[MAXC2];
+#pragma unroll
+        for (int u = 0; u < MAXC2; ++u) {  // all 2*MAXC2 16-byte loads of the lane in flight at once
+            const int c2 = base + tid + u * nt;
+            const bool in = c2 < ld2;
+            pv[u] = in ? prow2[c2] : make_double2(0.0, 0.0);
+            zv[u] = in ? zrow2[c2] : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int u = 0; u < MAXC2; ++u) {
+            const int c2 = base + tid + u * nt;
+            if (c2 < ld2) {
+                const int j = 2 * c2;
+                double2 q;
+                q.x = (j < C) ? pv[u].x / p : 0.0;      // :199 true division
+                q.y = (j + 1 < C) ? pv[u].y / p : 0.0;
+                out2[c2] = q;
+                const double mx = f0 * q.x;             // :208 product rounded ...
+                const double my = f0 * q.y;
+                const double zx = zv[u].x - mx;         // ... then the difference
+                const double zy = zv[u].y - my;
+                if (j < C - 1 && zx < n.v) {
+                    n.v = zx;
+                    n.i = j;
+                }
+                if (j + 1 < C - 1 && zy < n.v) {
+                    n.v = zy;
+                    n.i = j + 1;
+                }
+            }
+        }
+    }
+    n = block_cand_min(n, lds_v, lds_i);
+
+    if (tid == 0) {
+        st->cur_r = r;
+        st->cur_e = e;
+        st->next_e = n.i;
+        basis[r - 1] = e;  // :142
+        const int64_t it = st->iter;
+        if (it < st->log_cap) {
+            log[2 * it] = r;
+            log[2 * it + 1] = e;
+        }
+        st->iter = it + 1;  // :138
+        st->sweep ^= 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Rank-1 row elimination  PrimalSimplexSolver.cs:202-210
 //   T[i, j] = T[i, j] - (f_i * prow[j])   for i != r      (product rounded, then difference)
 //   T[r, j] = prow[j]                                       (the normalised row, :199)
@@ -189,14 +414,21 @@ template <int TR, int VPT, bool FULL>
 __device__ __forceinline__ void update_tile(double2* __restrict__ T2, int ld2, int R, int r,
                                             const double2* __restrict__ prow2,
                                             const double* __restrict__ colbuf, int i0,
-                                            int c2base) {
+                                            int c2base, int ne, int rhs,
+                                            double* __restrict__ next_col,
+                                            double* __restrict__ next_rhs) {
     double2 pr[VPT];
     bool ok[VPT];
+    // lanes that own the next entering column / the RHS column copy their new values into the
+    // dense vectors read by the next k_pivot_head (ne < 0: nothing to dump)
+    int dump_e = -1, dump_rhs = -1;
 #pragma unroll
     for (int v = 0; v < VPT; ++v) {
         const int c2 = c2base + v * 256;
         ok[v] = FULL || c2 < ld2;
         pr[v] = ok[v] ? prow2[c2] : make_double2(0.0, 0.0);
+        if (ne >= 0 && c2 == (ne >> 1)) dump_e = v;
+        if (ne >= 0 && c2 == (rhs >> 1)) dump_rhs = v;
     }
     double2 x[TR][VPT];
 #pragma unroll
@@ -224,6 +456,8 @@ __device__ __forceinline__ void update_tile(double2* __restrict__ T2, int ld2, i
                     o.y = x[k][v].y - py;
                     if (is_r) o = pr[v];            // the pivot row keeps the normalised values
                     T2[(size_t)i * ld2 + c2base + v * 256] = o;
+                    if (v == dump_e) next_col[i] = (ne & 1) ? o.y : o.x;
+                    if (v == dump_rhs) next_rhs[i] = (rhs & 1) ? o.y : o.x;
                 }
             }
         }
@@ -231,13 +465,16 @@ __device__ __forceinline__ void update_tile(double2* __restrict__ T2, int ld2, i
 }
 
 template <int TR, int VPT>
-__global__ __launch_bounds__(256) void k_update(double* __restrict__ T, int ld, int R,
+__global__ __launch_bounds__(256) void k_update(double* __restrict__ T, int ld, int R, int C,
                                                 const double* __restrict__ rowbuf,
                                                 const double* __restrict__ colbuf,
+                                                double* __restrict__ next_col,
+                                                double* __restrict__ next_rhs,
                                                 const PivotState* __restrict__ st,
-                                                int check_status, int serpentine) {
+                                                int check_status, int serpentine, int dump_next) {
     if (check_status && st->status != kRunning) return;
     const int r = st->cur_r;
+    const int ne = dump_next ? st->next_e : -1;
     const int ld2 = ld >> 1;
     int ct = blockIdx.x, rt = blockIdx.y;
     if (serpentine && (st->sweep & 1)) {  // reverse the sweep on alternate pivots
@@ -251,9 +488,11 @@ __global__ __launch_bounds__(256) void k_update(double* __restrict__ T, int ld, 
     // interior tiles (the common case) run without any per-element guard
     const bool full = (i0 + TR <= R) && ((ct + 1) * (256 * VPT) <= ld2);
     if (full)
-        update_tile<TR, VPT, true>(T2, ld2, R, r, prow2, colbuf, i0, c2base);
+        update_tile<TR, VPT, true>(T2, ld2, R, r, prow2, colbuf, i0, c2base, ne, C - 1, next_col,
+                                   next_rhs);
     else
-        update_tile<TR, VPT, false>(T2, ld2, R, r, prow2, colbuf, i0, c2base);
+        update_tile<TR, VPT, false>(T2, ld2, R, r, prow2, colbuf, i0, c2base, ne, C - 1,
+                                    next_col, next_rhs);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -361,29 +600,55 @@ void launch_select(lpr_tableau* t, int mode, int e_in, int r_in, int32_t* out_i)
                        r_in, out_i);
 }
 
+void launch_bootstrap(lpr_tableau* t) {
+    hipLaunchKernelGGL(k_bootstrap, dim3(1), dim3(1024), 0, t->eng->stream, t->T, t->ld, t->rows,
+                       t->cols, t->next_col, t->next_rhs, t->state);
+}
+
+template <int MAXC2>
+static void launch_pivot_head_t(lpr_tableau* t) {
+    hipLaunchKernelGGL((k_pivot_head<MAXC2>), dim3(1), dim3(1024), 0, t->eng->stream, t->T, t->ld,
+                       t->rows, t->cols, t->rowbuf, t->colbuf, t->next_col, t->next_rhs, t->basis,
+                       t->log, t->state);
+}
+
+// Pick the smallest instantiation that covers the row in one trip (MAXC2 = 8 keeps the 1024-thread
+// workgroup under its 128-VGPR budget; wider rows take several trips).
+void launch_pivot_head(lpr_tableau* t) {
+    const int need = (t->ld / 2 + 1023) / 1024;
+    if (need <= 1) launch_pivot_head_t<1>(t);
+    else if (need <= 2) launch_pivot_head_t<2>(t);
+    else if (need <= 4) launch_pivot_head_t<4>(t);
+    else launch_pivot_head_t<8>(t);
+}
+
 template <int TR, int VPT>
-static void launch_update_t(lpr_tableau* t, int check_status, int serpentine) {
+static void launch_update_t(lpr_tableau* t, int check_status, int serpentine, int dump_next) {
     const int ld2 = t->ld / 2;
     dim3 grid((ld2 + 256 * VPT - 1) / (256 * VPT), (t->rows + TR - 1) / TR);
     hipLaunchKernelGGL((k_update<TR, VPT>), grid, dim3(256), 0, t->eng->stream, t->T, t->ld,
-                       t->rows, t->rowbuf, t->colbuf, t->state, check_status, serpentine);
+                       t->rows, t->cols, t->rowbuf, t->colbuf, t->next_col, t->next_rhs, t->state,
+                       check_status, serpentine, dump_next);
 }
 
 // variant: low byte selects the tile shape, bit 8 turns the serpentine sweep on.
-int num_update_variants() { return 8; }
+int num_update_variants() { return 11; }
 
-void launch_update(lpr_tableau* t, int variant, int check_status) {
+void launch_update(lpr_tableau* t, int variant, int check_status, int dump_next) {
     const int serp = (variant >> 8) & 1;
     switch (variant & 0xff) {
         default:
-        case 0: launch_update_t<16, 1>(t, check_status, serp); break;
-        case 1: launch_update_t<8, 1>(t, check_status, serp); break;
-        case 2: launch_update_t<8, 2>(t, check_status, serp); break;
-        case 3: launch_update_t<4, 2>(t, check_status, serp); break;
-        case 4: launch_update_t<4, 4>(t, check_status, serp); break;
-        case 5: launch_update_t<32, 1>(t, check_status, serp); break;
-        case 6: launch_update_t<16, 2>(t, check_status, serp); break;
-        case 7: launch_update_t<2, 4>(t, check_status, serp); break;
+        case 0: launch_update_t<16, 1>(t, check_status, serp, dump_next); break;
+        case 1: launch_update_t<8, 1>(t, check_status, serp, dump_next); break;
+        case 2: launch_update_t<8, 2>(t, check_status, serp, dump_next); break;
+        case 3: launch_update_t<4, 2>(t, check_status, serp, dump_next); break;
+        case 4: launch_update_t<4, 4>(t, check_status, serp, dump_next); break;
+        case 5: launch_update_t<32, 1>(t, check_status, serp, dump_next); break;
+        case 6: launch_update_t<16, 2>(t, check_status, serp, dump_next); break;
+        case 7: launch_update_t<2, 4>(t, check_status, serp, dump_next); break;
+        case 8: launch_update_t<4, 1>(t, check_status, serp, dump_next); break;
+        case 9: launch_update_t<2, 1>(t, check_status, serp, dump_next); break;
+        case 10: launch_update_t<1, 1>(t, check_status, serp, dump_next); break;
     }
 }
 

@@ -135,7 +135,7 @@ def test_all_update_variants_and_paths_give_identical_bits(engine, oracle):
     T, basis = oracle.gen_dense_tableau(m, n, seed)
     st, piv, log = oracle.primal_solve(T, basis, 120)
     want = T.tobytes()
-    for variant in list(range(1, 9)) + [0x100 + v for v in range(1, 9)]:
+    for variant in list(range(1, 12)) + [0x100 + v for v in range(1, 12)]:
         for timed in (False, True):
             tab = Tableau.synthetic(engine, m, n, seed)
             res = tab.solve(max_pivots=120, variant=variant, time_kernels=timed, batch=32)
@@ -244,3 +244,19 @@ def test_edge_shapes(engine, oracle):
     s = PrimalSimplexSolver([3.0, 1.0], [Constraint([1.0, 1.0], "<=", 2.0)], False, engine=engine)
     s.Solve()
     assert s.Status == 0 and s.PivotLog.shape[0] == 0 and s.FinalZ == 0.0
+
+
+@pytest.mark.parametrize("m,n,seed", [(6, 20000, 1), (3000, 10, 2), (1, 1, 3), (2, 5000, 4),
+                                      (1500, 1, 5)])
+def test_extreme_aspect_ratios(engine, oracle, m, n, seed):
+    """Rows wider than one k_pivot_head trip (ld > 16384), very tall/thin tableaux, 1x1."""
+    from lpr_381_group_v22_amd import Tableau
+    T, basis = oracle.gen_dense_tableau(m, n, seed)
+    st, piv, log = oracle.primal_solve(T, basis, 3000)
+    tab = Tableau.synthetic(engine, m, n, seed)
+    res = tab.solve(max_pivots=3000)
+    assert res.status == st and res.pivots == piv
+    assert tab.pivot_log().tolist() == log.tolist()
+    assert tab.basis().tolist() == basis.tolist()
+    assert tab.read().tobytes() == T.tobytes()
+    tab.destroy()

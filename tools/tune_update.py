@@ -21,7 +21,7 @@ def main():
     m, n = args.m, args.n
     bytes_pp = 16 * (m + 1) * (n + m + 1)
     variants = [int(v, 0) for v in args.variants.split(",")] if args.variants else \
-        list(range(1, 9)) + [0x100 + v for v in range(1, 9)]
+        list(range(1, 12)) + [0x100 + v for v in range(1, 12)]
     eng = pkg.Engine(0)
     tab = pkg.Tableau.synthetic(eng, m, n, 0)
     tab.solve(max_pivots=16)
