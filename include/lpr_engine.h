@@ -110,8 +110,9 @@ int lpr_tableau_shape(const lpr_tableau* t, int* rows, int* cols, int* ld);
 /* Solver options.  Zero-initialise, then set fields; defaults equal the reference's literals. */
 typedef struct lpr_solve_opts {
     int64_t max_pivots;    /* <= 0: uncapped like PrimalSimplexSolver.cs:107 */
-    int32_t time_kernels;  /* != 0: launch eagerly and bracket every rank-1 update launch with HIP
-                              events on the engine stream; read back with lpr_tableau_kernel_stats */
+    int32_t time_kernels;  /* != 0: launch eagerly and bracket one rank-1 update launch in four with
+                              HIP events on the engine stream; read back with
+                              lpr_tableau_kernel_stats */
     int32_t batch;         /* pivots queued between host polls of the device status word (0: auto) */
     int32_t variant;       /* rank-1 update kernel variant (0: auto); for tuning only, same bits */
     int32_t reserved;

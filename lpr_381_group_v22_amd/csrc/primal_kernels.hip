@@ -299,34 +299,52 @@ __global__ __launch_bounds__(1024) void k_pivot_head(const double* __restrict__ 
         return;
     }
 
+    const int ld2 = ld >> 1;
+    const double2* __restrict__ zrow2 = reinterpret_cast<const double2*>(T);
+    double2* __restrict__ out2 = reinterpret_cast<double2*>(rowbuf);
+
+    // The Z-row slice of the first trip does not depend on the ratio test: issue its loads now so
+    // that they overlap the dense-vector loads below.
+    double2 zv[MAXC2];
+#pragma unroll
+    for (int u = 0; u < MAXC2; ++u) {
+        const int c2 = tid + u * nt;
+        zv[u] = (c2 < ld2) ? zrow2[c2] : make_double2(0.0, 0.0);
+    }
+
     // ---- FindLeavingVariable on the dense vectors ----
+    __shared__ double lds_p[2];  // [0] = T[r, e], [1] = T[0, e]
     Cand c;
     c.v = DBL_MAX;
     c.i = -1;
-    for (int i0 = tid; i0 < R; i0 += 4 * nt) {
-        double a[4], b[4];
+    double a_of_best = 0.0;  // next_col[c.i], carried so that p needs no second global read
+    for (int i0 = tid; i0 < R; i0 += 8 * nt) {
+        double a[8], b[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; ++u) {
             const int i = i0 + u * nt;
             const bool in = i < R;
             a[u] = in ? next_col[i] : 0.0;
             b[u] = in ? next_rhs[i] : 0.0;
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; ++u) {
             const int i = i0 + u * nt;
             if (i < R) {
                 colbuf[i] = a[u];
+                if (i == 0) lds_p[1] = a[u];
                 if (i >= 1 && a[u] > 1e-9) {
                     const double ratio = b[u] / a[u];
                     if (ratio >= 0 && ratio < c.v) {
                         c.v = ratio;
                         c.i = i;
+                        a_of_best = a[u];
                     }
                 }
             }
         }
     }
+    const int my_best = c.i;
     c = block_cand_min(c, lds_v, lds_i);
     const int r = c.i;
     if (r < 0) {
@@ -341,25 +359,29 @@ __global__ __launch_bounds__(1024) void k_pivot_head(const double* __restrict__ 
             return;
         }
     }
+    if (my_best == r) lds_p[0] = a_of_best;  // exactly one lane owns row r
+    __syncthreads();
 
     // ---- normalise row r, form the next Z row, pick the next entering column ----
-    const double p = next_col[r];   // T[r, e]
-    const double f0 = next_col[0];  // T[0, e]
-    const int ld2 = ld >> 1;
+    const double p = lds_p[0];   // T[r, e]
+    const double f0 = lds_p[1];  // T[0, e]
     const double2* __restrict__ prow2 = reinterpret_cast<const double2*>(T + (size_t)r * ld);
-    const double2* __restrict__ zrow2 = reinterpret_cast<const double2*>(T);
-    double2* __restrict__ out2 = reinterpret_cast<double2*>(rowbuf);
     Cand n;
     n.v = 0.0;
     n.i = -1;
     for (int base = 0; base < ld2; base += nt * MAXC2) {  // one trip when ld <= 2048 * MAXC2
-        double2 pv[MAXC2], zv[MAXC2];
+        double2 pv[MAXC2];
 #pragma unroll
-        for (int u = 0; u < MAXC2; ++u) {  // all 2*MAXC2 16-byte loads of the lane in flight at once
+        for (int u = 0; u < MAXC2; ++u) {  // all MAXC2 16-byte loads of the lane in flight at once
             const int c2 = base + tid + u * nt;
-            const bool in = c2 < ld2;
-            pv[u] = in ? prow2[c2] : make_double2(0.0, 0.0);
-            zv[u] = in ? zrow2[c2] : make_double2(0.0, 0.0);
+            pv[u] = (c2 < ld2) ? prow2[c2] : make_double2(0.0, 0.0);
+        }
+        if (base > 0) {
+#pragma unroll
+            for (int u = 0; u < MAXC2; ++u) {
+                const int c2 = base + tid + u * nt;
+                zv[u] = (c2 < ld2) ? zrow2[c2] : make_double2(0.0, 0.0);
+            }
         }
 #pragma unroll
         for (int u = 0; u < MAXC2; ++u) {

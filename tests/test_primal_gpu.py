@@ -144,7 +144,7 @@ def test_all_update_variants_and_paths_give_identical_bits(engine, oracle):
             assert tab.read().tobytes() == want, (variant, timed)
             if timed:
                 launches, total_ms, avg_ms = tab.kernel_stats()
-                assert launches == piv and total_ms > 0 and avg_ms > 0
+                assert 0 < launches <= piv and total_ms > 0 and avg_ms > 0
             tab.destroy()
 
 
