@@ -59,6 +59,18 @@ int orc_primal_solve(double* T, int R, int C, int32_t* basis, int64_t max_pivots
                      int32_t* log_rows, int32_t* log_cols, int64_t log_cap, int64_t* pivots);
 void orc_extract_solution(const double* T, int R, int C, int n, double* x, double* z); /* :213-252 */
 
+/* ---- RevisedPrimalSimplexSolver (Simplex/RevisedPrimalSimplexSolver.cs) ---- */
+/* MultiplyMatrices :426-441 (zero-skip |a_ik| < 1e-9): R(rA x cB) = A(rA x cA) * B(cA x cB).
+ * With (BInverse, A) this is the snapshot product of :360 -- BASELINE's "B^-1 * A". */
+void orc_matmul_skip(const double* A, int rA, int cA, const double* B, int cB, double* R);
+/* UpdateBInverse :264-275 (scratch: m*m doubles).  0 or ORC_PIVOT_TOO_SMALL. */
+int orc_update_binverse(double* Binv, int m, int pivotRow, const double* u, double* scratch);
+/* ctor :41-80 + Solve :82-251 + ExtractSolution :277-287; see oracle_revised.c */
+int orc_revised_solve(int n, int m, const double* objective, const double* A, const double* b,
+                      int is_min, int64_t max_iter, double* x, double* finalZ, int32_t* basis,
+                      double* Binv_out, double* xB_out, int32_t* log_row, int32_t* log_enter,
+                      int32_t* log_leave, int64_t log_cap, int64_t* iterations);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,239 @@
+/*
+ * oracle_revised.c -- literal CPU restatement of RevisedPrimalSimplexSolver
+ * (reference: LPR_381_Group_V22/Simplex/RevisedPrimalSimplexSolver.cs).
+ *
+ * TEST INFRASTRUCTURE ONLY -- see lpr_oracle.h.  PARITY UNPINNED by the reference (no tests, no
+ * golden vectors); pinned by tests/ref_py.py + the SURVEY.md section 4 hand trace.
+ *
+ * Every sum is the C#'s sequential ascending-index loop with the product rounded before the add
+ * (`s += a * b`), every comparator is the C#'s EPS-band sequential fold.  The `B` matrix the C#
+ * maintains (:201-212) is never read by it and is not kept here.
+ */
+#include "lpr_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define EPS 1e-9 /* :12 */
+
+/* MultiplyMatrixVector :398-410 */
+static void mat_vec(const double* M, int rows, int cols, const double* v, double* r) {
+    for (int i = 0; i < rows; i++) {
+        double s = 0;
+        for (int j = 0; j < cols; j++) s += M[(size_t)i * cols + j] * v[j];
+        r[i] = s;
+    }
+}
+
+/* MultiplyVectorMatrix :412-424 */
+static void vec_mat(const double* v, const double* M, int rows, int cols, double* r) {
+    for (int j = 0; j < cols; j++) {
+        double s = 0;
+        for (int i = 0; i < rows; i++) s += v[i] * M[(size_t)i * cols + j];
+        r[j] = s;
+    }
+}
+
+/* Dot :443-448 */
+static double dot(const double* a, const double* b, int n) {
+    double s = 0;
+    for (int i = 0; i < n; i++) s += a[i] * b[i];
+    return s;
+}
+
+/* MultiplyMatrices :426-441 -- R = A(rA x cA) * B(cA x cB) with the zero-skip on |a_ik| < EPS.
+ * This is the `BInvA = MultiplyMatrices(BInverse, A)` of CaptureSnapshot (:360) when called with
+ * (BInverse, A), and the `E * BInverse` of UpdateBInverse (:274). */
+void orc_matmul_skip(const double* A, int rA, int cA, const double* B, int cB, double* R) {
+    memset(R, 0, (size_t)rA * cB * sizeof(double));
+    for (int i = 0; i < rA; i++)
+        for (int k = 0; k < cA; k++) {
+            double aik = A[(size_t)i * cA + k];
+            if (fabs(aik) < EPS) continue;
+            const double* brow = B + (size_t)k * cB;
+            double* rrow = R + (size_t)i * cB;
+            for (int j = 0; j < cB; j++) {
+                double prod = aik * brow[j];
+                rrow[j] = rrow[j] + prod;
+            }
+        }
+}
+
+/* UpdateBInverse :264-275.  E is the identity with column `pivotRow` replaced (:269-272); the
+ * product E * BInverse is formed by the same i-k-j loops as MultiplyMatrices, generating E[i,k] on
+ * the fly instead of materialising the m x m matrix.  Returns 0, or ORC_PIVOT_TOO_SMALL. */
+int orc_update_binverse(double* Binv, int m, int pivotRow, const double* u, double* scratch) {
+    double pivot = u[pivotRow];
+    if (fabs(pivot) < EPS) return ORC_PIVOT_TOO_SMALL; /* :267 */
+    double* R = scratch;
+    memset(R, 0, (size_t)m * m * sizeof(double));
+    for (int i = 0; i < m; i++) {
+        double* rrow = R + (size_t)i * m;
+        for (int k = 0; k < m; k++) {
+            double aik;
+            if (k == pivotRow) aik = (i == pivotRow) ? 1.0 / pivot : -u[i] / pivot; /* :272 */
+            else aik = (i == k) ? 1.0 : 0.0;                                       /* :270 */
+            if (fabs(aik) < EPS) continue;
+            const double* brow = Binv + (size_t)k * m;
+            for (int j = 0; j < m; j++) {
+                double prod = aik * brow[j];
+                rrow[j] = rrow[j] + prod;
+            }
+        }
+    }
+    memcpy(Binv, R, (size_t)m * m * sizeof(double));
+    return 0;
+}
+
+/* .NET Framework Math.Max(double, double): `if (a > b) return a; if (IsNaN(a)) return a; return b;` */
+static double dotnet_max0(double v) { return (0.0 > v) ? 0.0 : v; }
+
+/*
+ * Solve :82-251 (+ ctor :41-80, ExtractSolution :277-287).
+ *   objective[n], A[m*n] row-major, b[m]; every constraint is treated as "<=" (Relation is never
+ *   read by the reference).  is_min: c = -cOrig (:51).
+ * Outputs (any may be NULL): x[n], *finalZ, basis[m], Binv_out[m*m], xB_out[m];
+ *   log_row/log_enter/log_leave: per iteration (leavingRow 0-based, entering var, leaving var).
+ * Returns the status; *iterations = completed pivots.
+ */
+int orc_revised_solve(int n, int m, const double* objective, const double* A, const double* b,
+                      int is_min, int64_t max_iter, double* x, double* finalZ, int32_t* basis,
+                      double* Binv_out, double* xB_out, int32_t* log_row, int32_t* log_enter,
+                      int32_t* log_leave, int64_t log_cap, int64_t* iterations) {
+    if (n <= 0 || m <= 0) return ORC_BAD_ARGUMENT; /* :43-44 */
+    int status = ORC_OK_OPTIMAL;
+    double* c = (double*)malloc(sizeof(double) * n);
+    double* Binv = (double*)calloc((size_t)m * m, sizeof(double));
+    double* scratch = (double*)malloc(sizeof(double) * (size_t)m * m);
+    double* cB = (double*)calloc(m, sizeof(double));
+    double* xB = (double*)calloc(m, sizeof(double));
+    double* y = (double*)malloc(sizeof(double) * m);
+    double* rcX = (double*)malloc(sizeof(double) * n);
+    double* rcS = (double*)malloc(sizeof(double) * m);
+    double* col = (double*)malloc(sizeof(double) * m);
+    double* u = (double*)malloc(sizeof(double) * m);
+    int* basic = (int*)malloc(sizeof(int) * m);
+    int* nonbasic = (int*)malloc(sizeof(int) * (n + m)); /* the C# List<int>, in its own order */
+    int* sorted = (int*)malloc(sizeof(int) * (n + m));
+    int nnb = 0;
+    int64_t iteration = 0;
+
+    for (int j = 0; j < n; j++) c[j] = is_min ? -objective[j] : objective[j]; /* :51 */
+    for (int i = 0; i < m; i++) { /* :72-78 */
+        Binv[(size_t)i * m + i] = 1.0;
+        basic[i] = n + i;
+        cB[i] = 0.0;
+    }
+    for (int j = 0; j < n; j++) nonbasic[nnb++] = j; /* :79 */
+
+    for (;;) {
+        mat_vec(Binv, m, m, b, xB); /* :89 */
+        int infeasible = 0;
+        for (int i = 0; i < m; i++) if (xB[i] < -EPS) { infeasible = 1; break; } /* :90 */
+        if (infeasible) { status = ORC_INFEASIBLE_BASIS; break; }
+
+        vec_mat(cB, Binv, m, m, y); /* :93 */
+
+        for (int j = 0; j < n; j++) { /* :96-98  rc = c_j - Dot(y, GetColumn(A, j)) */
+            for (int i = 0; i < m; i++) col[i] = A[(size_t)i * n + j];
+            rcX[j] = c[j] - dot(y, col, m);
+        }
+        for (int k = 0; k < m; k++) rcS[k] = -y[k]; /* :100-102 */
+
+        /* :105-121 entering: nonBasicVariables.OrderBy(v => v) (stable; values are distinct) */
+        memcpy(sorted, nonbasic, sizeof(int) * nnb);
+        for (int a = 1; a < nnb; a++) { /* insertion sort: the list is almost sorted */
+            int v = sorted[a], k = a - 1;
+            while (k >= 0 && sorted[k] > v) { sorted[k + 1] = sorted[k]; k--; }
+            sorted[k + 1] = v;
+        }
+        int enteringIdx = -1;
+        double bestPosRC = -INFINITY;
+        for (int q = 0; q < nnb; q++) {
+            int vIdx = sorted[q];
+            double rc = (vIdx < n) ? rcX[vIdx] : rcS[vIdx - n];
+            if (rc > EPS) {
+                if (enteringIdx == -1 || rc > bestPosRC + EPS ||
+                    (fabs(rc - bestPosRC) <= EPS && vIdx < enteringIdx)) {
+                    bestPosRC = rc;
+                    enteringIdx = vIdx;
+                }
+            }
+        }
+
+        if (enteringIdx == -1) { status = ORC_OK_OPTIMAL; break; } /* :124-146 */
+        if (max_iter > 0 && iteration >= max_iter) { status = ORC_PIVOT_LIMIT; break; }
+
+        /* :149-151 direction */
+        if (enteringIdx < n) {
+            for (int i = 0; i < m; i++) col[i] = A[(size_t)i * n + enteringIdx];
+            mat_vec(Binv, m, m, col, u);
+        } else {
+            int k = enteringIdx - n;
+            for (int i = 0; i < m; i++) u[i] = Binv[(size_t)i * m + k];
+        }
+
+        /* :154-176 ratio test */
+        int leavingRow = -1;
+        double bestRatio = DBL_MAX;
+        for (int i = 0; i < m; i++) {
+            if (u[i] > EPS) {
+                double ratio = xB[i] / u[i];
+                if (ratio < bestRatio - EPS ||
+                    (fabs(ratio - bestRatio) <= EPS &&
+                     (leavingRow == -1 || basic[i] < basic[leavingRow]))) {
+                    bestRatio = ratio;
+                    leavingRow = i;
+                }
+            }
+        }
+        if (leavingRow == -1) { status = ORC_UNBOUNDED; break; } /* :178-179 */
+        int leavingVar = basic[leavingRow];
+        if (leavingVar == enteringIdx) { status = ORC_ENTERING_ALREADY_BASIC; break; } /* :182-183 */
+
+        if (iteration < log_cap) {
+            if (log_row) log_row[iteration] = leavingRow;
+            if (log_enter) log_enter[iteration] = enteringIdx;
+            if (log_leave) log_leave[iteration] = leavingVar;
+        }
+
+        /* :194-198 bookkeeping */
+        basic[leavingRow] = enteringIdx;
+        for (int q = 0; q < nnb; q++)
+            if (nonbasic[q] == enteringIdx) { /* List.Remove: first occurrence */
+                memmove(nonbasic + q, nonbasic + q + 1, sizeof(int) * (nnb - q - 1));
+                nnb--;
+                break;
+            }
+        int contains = 0;
+        for (int q = 0; q < nnb; q++) if (nonbasic[q] == leavingVar) { contains = 1; break; }
+        if (!contains) nonbasic[nnb++] = leavingVar;
+
+        cB[leavingRow] = (enteringIdx < n) ? c[enteringIdx] : 0.0; /* :205,211 */
+
+        int rc2 = orc_update_binverse(Binv, m, leavingRow, u, scratch); /* :215 */
+        if (rc2 != 0) { status = rc2; break; }
+        iteration++; /* :249 */
+    }
+
+    if (status == ORC_OK_OPTIMAL) { /* ExtractSolution :277-287 */
+        double* xs = (double*)calloc(n, sizeof(double));
+        for (int i = 0; i < m; i++) {
+            int v = basic[i];
+            if (v < n) xs[v] = dotnet_max0(xB[i]);
+        }
+        if (x) memcpy(x, xs, sizeof(double) * n);
+        if (finalZ) *finalZ = dot(objective, xs, n); /* Dot(cOrig, x) */
+        free(xs);
+    }
+    if (basis) for (int i = 0; i < m; i++) basis[i] = basic[i];
+    if (Binv_out) memcpy(Binv_out, Binv, sizeof(double) * (size_t)m * m);
+    if (xB_out) memcpy(xB_out, xB, sizeof(double) * m);
+    if (iterations) *iterations = iteration;
+
+    free(c); free(Binv); free(scratch); free(cB); free(xB); free(y); free(rcX); free(rcS);
+    free(col); free(u); free(basic); free(nonbasic); free(sorted);
+    return status;
+}

@@ -63,6 +63,50 @@ class Oracle:
         lib.orc_extract_solution.restype = None
         lib.orc_extract_solution.argtypes = [_D, C.c_int, C.c_int, C.c_int, _D, _D]
 
+        lib.orc_matmul_skip.restype = None
+        lib.orc_matmul_skip.argtypes = [_D, C.c_int, C.c_int, _D, C.c_int, _D]
+        lib.orc_update_binverse.restype = C.c_int
+        lib.orc_update_binverse.argtypes = [_D, C.c_int, C.c_int, _D, _D]
+        lib.orc_revised_solve.restype = C.c_int
+        lib.orc_revised_solve.argtypes = [C.c_int, C.c_int, _D, _D, _D, C.c_int, C.c_int64, _D,
+                                          _D, _I32, _D, _D, _I32, _I32, _I32, C.c_int64, _I64]
+
+    # ---- revised ----
+    def matmul_skip(self, A, B):
+        A = np.ascontiguousarray(A, dtype=np.float64)
+        B = np.ascontiguousarray(B, dtype=np.float64)
+        R = np.zeros((A.shape[0], B.shape[1]))
+        self.lib.orc_matmul_skip(_dp(A), A.shape[0], A.shape[1], _dp(B), B.shape[1], _dp(R))
+        return R
+
+    def update_binverse(self, Binv, pivot_row, u):
+        """In place on Binv; returns 0 or ORC_PIVOT_TOO_SMALL."""
+        m = Binv.shape[0]
+        scratch = np.zeros((m, m))
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        return self.lib.orc_update_binverse(_dp(Binv), m, pivot_row, _dp(u), _dp(scratch))
+
+    def revised_solve(self, objective, A, b, is_min=False, max_iter=0, log_cap=1 << 16):
+        obj = np.ascontiguousarray(objective, dtype=np.float64)
+        A = np.ascontiguousarray(A, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        m, n = A.shape
+        x = np.zeros(n)
+        z = C.c_double()
+        basis = np.zeros(m, dtype=np.int32)
+        Binv = np.zeros((m, m))
+        xB = np.zeros(m)
+        lr = np.zeros(log_cap, dtype=np.int32)
+        le = np.zeros(log_cap, dtype=np.int32)
+        ll = np.zeros(log_cap, dtype=np.int32)
+        it = C.c_int64()
+        st = self.lib.orc_revised_solve(n, m, _dp(obj), _dp(A), _dp(b), 1 if is_min else 0,
+                                        max_iter, _dp(x), C.byref(z), _ip(basis), _dp(Binv),
+                                        _dp(xB), _ip(lr), _ip(le), _ip(ll), log_cap, C.byref(it))
+        k = min(it.value, log_cap)
+        return dict(status=st, iterations=it.value, x=x, z=z.value, basis=basis, Binv=Binv,
+                    xB=xB, log=np.stack([lr[:k], le[:k], ll[:k]], axis=1))
+
     # ---- generator ----
     def u01(self, seed, stream, i, j) -> float:
         return self.lib.orc_u01(seed, stream, i, j)

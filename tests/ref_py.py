@@ -152,6 +152,155 @@ def _div(a: float, b: float) -> float:
 
 
 # --------------------------------------------------------------------------------------------
+# Simplex/RevisedPrimalSimplexSolver.cs
+# --------------------------------------------------------------------------------------------
+REV_EPS = 1e-9
+
+
+def _mat_vec(M, v):  # :398-410
+    out = []
+    for row in M:
+        s = 0.0
+        for j in range(len(row)):
+            s += row[j] * v[j]
+        out.append(s)
+    return out
+
+
+def _vec_mat(v, M):  # :412-424
+    rows = len(M)
+    cols = len(M[0])
+    out = []
+    for j in range(cols):
+        s = 0.0
+        for i in range(rows):
+            s += v[i] * M[i][j]
+        out.append(s)
+    return out
+
+
+def _dot(a, b):  # :443-448
+    s = 0.0
+    for i in range(len(a)):
+        s += a[i] * b[i]
+    return s
+
+
+def _mat_mul_skip(A, B):  # :426-441
+    rA, cA, cB = len(A), len(A[0]), len(B[0])
+    R = [[0.0] * cB for _ in range(rA)]
+    for i in range(rA):
+        for k in range(cA):
+            aik = A[i][k]
+            if abs(aik) < REV_EPS:
+                continue
+            Bk = B[k]
+            Ri = R[i]
+            for j in range(cB):
+                Ri[j] += aik * Bk[j]
+    return R
+
+
+class PyRevised:
+    """ctor :41-80, Solve :82-251, UpdateBInverse :264-275, ExtractSolution :277-287."""
+
+    def __init__(self, objective, constraints, is_min):
+        if not objective or not constraints:
+            raise ValueError("empty")
+        self.n = n = len(objective)
+        self.m = m = len(constraints)
+        self.is_min = is_min
+        self.cOrig = list(objective)
+        self.c = [-v for v in objective] if is_min else list(objective)
+        self.A = []
+        self.b = []
+        for i, con in enumerate(constraints):
+            if len(con.Coefficients) != n:
+                raise ValueError(f"Constraint {i + 1} has incorrect number of coefficients.")
+            self.A.append(list(con.Coefficients))
+            self.b.append(con.RHS)
+        self.basic = [n + i for i in range(m)]
+        self.nonbasic = list(range(n))
+        self.Binv = [[1.0 if i == j else 0.0 for j in range(m)] for i in range(m)]
+        self.cB = [0.0] * m
+        self.xB = [0.0] * m
+        self.log = []
+        self.status = None
+        self.FinalZ = 0.0
+        self.SolutionVector = []
+
+    def solve(self, max_iter=0):
+        n, m = self.n, self.m
+        it = 0
+        while True:
+            self.xB = _mat_vec(self.Binv, self.b)
+            if any(v < -REV_EPS for v in self.xB):
+                self.status = "infeasible_basis"
+                return self.status
+            y = _vec_mat(self.cB, self.Binv)
+            rcX = [self.c[j] - _dot(y, [self.A[i][j] for i in range(m)]) for j in range(n)]
+            rcS = [-y[k] for k in range(m)]
+            entering = -1
+            best = -math.inf
+            for v in sorted(self.nonbasic):
+                rc = rcX[v] if v < n else rcS[v - n]
+                if rc > REV_EPS:
+                    if entering == -1 or rc > best + REV_EPS or \
+                            (abs(rc - best) <= REV_EPS and v < entering):
+                        best = rc
+                        entering = v
+            if entering == -1:
+                x = [0.0] * n
+                for i in range(m):
+                    v = self.basic[i]
+                    if v < n:
+                        x[v] = 0.0 if 0.0 > self.xB[i] else self.xB[i]  # Math.Max(0.0, xB)
+                self.SolutionVector = x
+                self.FinalZ = _dot(self.cOrig, x)
+                self.status = "optimal"
+                return self.status
+            if max_iter > 0 and it >= max_iter:
+                self.status = "limit"
+                return self.status
+            if entering < n:
+                u = _mat_vec(self.Binv, [self.A[i][entering] for i in range(m)])
+            else:
+                u = [self.Binv[i][entering - n] for i in range(m)]
+            leaving = -1
+            best_ratio = DBL_MAX
+            for i in range(m):
+                if u[i] > REV_EPS:
+                    ratio = self.xB[i] / u[i]
+                    if ratio < best_ratio - REV_EPS or \
+                            (abs(ratio - best_ratio) <= REV_EPS and
+                             (leaving == -1 or self.basic[i] < self.basic[leaving])):
+                        best_ratio = ratio
+                        leaving = i
+            if leaving == -1:
+                self.status = "unbounded"
+                return self.status
+            leaving_var = self.basic[leaving]
+            if leaving_var == entering:
+                self.status = "entering_already_basic"
+                return self.status
+            self.log.append((leaving, entering, leaving_var))
+            self.basic[leaving] = entering
+            self.nonbasic.remove(entering)
+            if leaving_var not in self.nonbasic:
+                self.nonbasic.append(leaving_var)
+            self.cB[leaving] = self.c[entering] if entering < n else 0.0
+            pivot = u[leaving]
+            if abs(pivot) < REV_EPS:
+                self.status = "pivot_too_small"
+                return self.status
+            E = [[1.0 if i == j else 0.0 for j in range(m)] for i in range(m)]
+            for i in range(m):
+                E[i][leaving] = (1.0 / pivot) if i == leaving else (-u[i] / pivot)
+            self.Binv = _mat_mul_skip(E, self.Binv)
+            it += 1
+
+
+# --------------------------------------------------------------------------------------------
 # Program.cs glue that shapes the solver inputs
 # --------------------------------------------------------------------------------------------
 def program_option1_constraints(n: int, constraints: List[PyConstraint]) -> List[PyConstraint]:

@@ -1,0 +1,105 @@
+"""CPU tests: the C oracle of RevisedPrimalSimplexSolver against the independent Python restatement,
+the SURVEY.md section 4 hand trace and scipy.  PARITY UNPINNED by the reference (no tests there)."""
+import struct
+
+import numpy as np
+import pytest
+
+import lp_cases
+from ref_py import PyConstraint, PyRevised, parse_model_text, program_option2_constraints
+
+STATUS = {0: "optimal", 1: "unbounded", 2: "infeasible_basis", 3: "pivot_too_small",
+          4: "entering_already_basic", 5: "limit"}
+
+
+def bits(x):
+    return struct.pack(">d", float(x)).hex()
+
+
+def sample_option2():
+    ptype, obj, cons, signs = parse_model_text(lp_cases.SAMPLE_MODEL)
+    return obj, program_option2_constraints(len(obj), signs, cons), ptype == "min"
+
+
+def revised_cases():
+    cases = [("sample_option2", sample_option2())]
+    for (m, n, seed) in [(4, 8, 0), (16, 32, 1), (24, 12, 2), (48, 64, 3)]:
+        obj, cons, _ = lp_cases.random_dense(m, n, seed)
+        cases.append((f"dense_{m}x{n}_s{seed}", (obj, cons, False)))
+    for (m, n, seed) in [(6, 6, 0), (12, 9, 1), (24, 30, 2), (33, 20, 3)]:
+        obj, cons, _ = lp_cases.tie_heavy(m, n, seed)
+        cases.append((f"ties_{m}x{n}_s{seed}", (obj, cons, False)))
+    obj, cons, _ = lp_cases.unbounded_lp()
+    cases.append(("unbounded", (obj, cons, False)))
+    obj, cons, _ = lp_cases.min_lp()
+    cases.append(("min_lp", (obj, cons, True)))
+    # a negative right-hand side trips "Infeasible basis" on the first iteration (:90-91)
+    cases.append(("infeasible_basis", ([1.0, 1.0], [PyConstraint([1.0, 1.0], "<=", -1.0)], False)))
+    obj, cons, _ = lp_cases.klee_minty_bounded(8)
+    cases.append(("klee_minty_8", (obj, cons, False)))
+    return cases
+
+
+def flat(cons):
+    return (np.array([c.Coefficients for c in cons], dtype=np.float64),
+            np.array([c.RHS for c in cons], dtype=np.float64))
+
+
+@pytest.mark.parametrize("name,case", revised_cases(), ids=[c[0] for c in revised_cases()])
+def test_oracle_equals_python_restatement(oracle, name, case):
+    obj, cons, is_min = case
+    A, b = flat(cons)
+    r = oracle.revised_solve(obj, A, b, is_min, max_iter=3000)
+    p = PyRevised(obj, cons, is_min)
+    ps = p.solve(max_iter=3000)
+    assert ps == STATUS[r["status"]]
+    assert [tuple(v) for v in r["log"].tolist()] == p.log
+    assert r["basis"].tolist() == p.basic
+    assert np.array(p.Binv).tobytes() == r["Binv"].tobytes()
+    assert np.array(p.xB).tobytes() == r["xB"].tobytes()
+    if ps == "optimal":
+        assert bits(p.FinalZ) == bits(r["z"])
+        assert [bits(v) for v in p.SolutionVector] == [bits(v) for v in r["x"]]
+
+
+def test_survey_hand_trace_sample_option2(oracle):
+    """data/TextFile.txt through Program.cs option 2."""
+    obj, cons, is_min = sample_option2()
+    assert len(cons) == 7 and not is_min
+    A, b = flat(cons)
+    r = oracle.revised_solve(obj, A, b, is_min)
+    assert r["status"] == 0
+    assert bits(r["z"]) == bits(15.399999999999999)
+    assert bits(r["x"][4]) == bits(0.19999999999999973)
+    assert r["log"].tolist() == [[4, 3, 10], [6, 5, 12], [2, 1, 8], [3, 2, 9], [0, 0, 6],
+                                 [0, 4, 0]]
+    assert sorted(r["basis"].tolist()) == sorted([4, 7, 1, 2, 3, 11, 5])
+
+
+def test_objective_against_scipy(oracle):
+    from scipy.optimize import linprog
+    for (m, n, seed) in [(4, 8, 0), (16, 32, 1), (48, 64, 3)]:
+        obj, cons, _ = lp_cases.random_dense(m, n, seed)
+        A, b = flat(cons)
+        r = oracle.revised_solve(obj, A, b, False)
+        assert r["status"] == 0
+        ref = linprog(-np.array(obj), A_ub=A, b_ub=b, bounds=(0, None), method="highs")
+        assert abs(r["z"] - (-ref.fun)) <= 1e-9 * max(1.0, abs(ref.fun))
+
+
+def test_matmul_skip_semantics(oracle):
+    """MultiplyMatrices :426-441: entries of the left factor below 1e-9 in magnitude are skipped."""
+    rng = np.random.RandomState(0)
+    A = rng.randn(7, 5)
+    A[2, 3] = 5e-10
+    A[4, 0] = -9.99e-10
+    B = rng.randn(5, 9)
+    R = oracle.matmul_skip(A, B)
+    Az = np.where(np.abs(A) < 1e-9, 0.0, A)
+    want = np.zeros((7, 9))
+    for i in range(7):
+        for k in range(5):
+            if Az[i, k] != 0.0:
+                want[i] = want[i] + Az[i, k] * B[k]
+    assert R.tobytes() == want.tobytes()
+    assert not np.array_equal(R, A @ B)
