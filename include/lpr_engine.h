@@ -159,6 +159,56 @@ int lpr_pivot_log_read(lpr_tableau* t, int32_t* rows_out, int32_t* cols_out, int
  * launches, summed and average duration in milliseconds (HIP events on the engine stream). */
 int lpr_tableau_kernel_stats(lpr_tableau* t, int64_t* launches, double* total_ms, double* avg_ms);
 
+/* -------------------------------------------------- revised primal simplex */
+
+typedef struct lpr_revised lpr_revised;
+
+/* Replaces `new RevisedPrimalSimplexSolver(objective, constraints, isMinimization)`
+ * (Simplex/RevisedPrimalSimplexSolver.cs:41-80): c = -objective if is_min (:51), dense A[m, n] and
+ * b[m] copied to HBM, B^-1 = I, basis = slacks.  Every row is treated as "<=": the reference never
+ * reads Constraint.Relation here.  The C# ArgumentExceptions (:43-44, :57-58: empty objective /
+ * constraints, wrong coefficient count) are LPR_BAD_ARGUMENT; the row-length check is the
+ * caller's because A arrives already flattened (lda >= n). */
+int lpr_revised_create(lpr_engine* e, int n, int m, const double* objective, const double* A,
+                       int lda, const double* b, int is_min, lpr_revised** out);
+/* The synthetic dense LP of lpr_tableau_synthetic in (c, A, b) form, generated on the device. */
+int lpr_revised_synthetic(lpr_engine* e, int m, int n, uint64_t seed, lpr_revised** out);
+int lpr_revised_destroy(lpr_revised* s);
+
+typedef struct lpr_revised_result {
+    int32_t status;           /* lpr_status; the C# throws for 1..4 with the messages of
+                                 :91 / :179 / :183 / :267 -- the host mirror re-raises them */
+    int32_t reserved;
+    int64_t iterations;       /* pivots performed by THIS call */
+    int64_t total_iterations; /* pivots so far (the C# `iteration`, :249) */
+    double z;                 /* FinalZ = Dot(cOrig, x) (:286); valid when status == OPTIMAL */
+} lpr_revised_result;
+
+/* Replaces RevisedPrimalSimplexSolver.Solve() (:82-251) + ExtractSolution (:277-287).  Per
+ * iteration: x_B = B^-1 b, feasibility, y = c_B B^-1, reduced costs, entering fold (:105-121),
+ * u = B^-1 a_e, ratio fold (:154-176), bookkeeping, B^-1 <- E B^-1 (:264-275).  All sums in the
+ * C#'s sequential order, all on the device.  Only opts->max_pivots and opts->batch are used. */
+int lpr_revised_solve(lpr_revised* s, const lpr_solve_opts* opts, lpr_revised_result* res);
+
+/* SolutionVector / FinalZ (:36-38): x has n entries.  Valid after an OPTIMAL solve. */
+int lpr_revised_solution(lpr_revised* s, double* x, double* z);
+/* BasicVariables (:39): m entries, by basis row. */
+int lpr_revised_basis_read(lpr_revised* s, int32_t* basis_out);
+/* Pivot log: (leavingRow 0-based, entering variable, leaving variable) per iteration. */
+int lpr_revised_log_read(lpr_revised* s, int32_t* row_out, int32_t* enter_out,
+                         int32_t* leave_out, int64_t cap, int64_t* count);
+/* BInverse (m x m row-major) and the last x_B (m), for snapshots and tests. */
+int lpr_revised_binv_read(lpr_revised* s, double* out);
+int lpr_revised_xb_read(lpr_revised* s, double* out);
+
+/* Replaces `MultiplyMatrices(BInverse, A)` of CaptureSnapshot (:360, helper :426-441, zero-skip
+ * |b_ik| < 1e-9): the m x n product B^-1 * A, computed on the fp64 matrix cores
+ * (v_mfma_f64_16x16x4_f64).  out (m x n row-major) may be NULL to keep the product on the device
+ * (benchmarking); *ms, if not NULL, receives the kernel time in milliseconds (HIP events).
+ * This product only feeds the printed tableau, so its contract is a tolerance
+ * (|err| <= 1e-9 * sum_k |b_ik a_kj|), not bit equality -- DESIGN.md. */
+int lpr_revised_binv_a(lpr_revised* s, double* out, double* ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -4,11 +4,13 @@ Importing this package loads ``_lib/liblpr_engine.so`` (hand-written HIP for gfx
 ``__graft_entry__.build()``); there is no CPU fallback.
 """
 from . import _native
-from .engine import Engine, Tableau, default_engine
+from .engine import Engine, RevisedState, Tableau, default_engine
 from .input_file_parser import Constraint, InputFileParser
 from .primal_simplex_solver import PrimalSimplexSolver
+from .revised_primal_simplex_solver import RevisedPrimalSimplexSolver, SolverException
 
 __all__ = [
     "Engine", "Tableau", "default_engine", "Constraint", "InputFileParser",
-    "PrimalSimplexSolver", "_native",
+    "PrimalSimplexSolver", "RevisedPrimalSimplexSolver", "RevisedState", "SolverException",
+    "_native",
 ]

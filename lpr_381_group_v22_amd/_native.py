@@ -53,6 +53,16 @@ class SolveResult(C.Structure):
     ]
 
 
+class RevisedResult(C.Structure):
+    _fields_ = [
+        ("status", C.c_int32),
+        ("reserved", C.c_int32),
+        ("iterations", C.c_int64),
+        ("total_iterations", C.c_int64),
+        ("z", C.c_double),
+    ]
+
+
 _P = C.c_void_p
 _PP = C.POINTER(C.c_void_p)
 _D = C.POINTER(C.c_double)
@@ -86,6 +96,16 @@ SIGNATURES = {
     "lpr_basis_read": (C.c_int, [_P, _I32]),
     "lpr_pivot_log_read": (C.c_int, [_P, _I32, _I32, C.c_int64, _I64]),
     "lpr_tableau_kernel_stats": (C.c_int, [_P, _I64, _D, _D]),
+    "lpr_revised_create": (C.c_int, [_P, C.c_int, C.c_int, _D, _D, C.c_int, _D, C.c_int, _PP]),
+    "lpr_revised_synthetic": (C.c_int, [_P, C.c_int, C.c_int, C.c_uint64, _PP]),
+    "lpr_revised_destroy": (C.c_int, [_P]),
+    "lpr_revised_solve": (C.c_int, [_P, C.POINTER(SolveOpts), C.POINTER(RevisedResult)]),
+    "lpr_revised_solution": (C.c_int, [_P, _D, _D]),
+    "lpr_revised_basis_read": (C.c_int, [_P, _I32]),
+    "lpr_revised_log_read": (C.c_int, [_P, _I32, _I32, _I32, C.c_int64, _I64]),
+    "lpr_revised_binv_read": (C.c_int, [_P, _D]),
+    "lpr_revised_xb_read": (C.c_int, [_P, _D]),
+    "lpr_revised_binv_a": (C.c_int, [_P, _D, _D]),
 }
 
 

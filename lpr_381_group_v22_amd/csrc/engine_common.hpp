@@ -58,6 +58,7 @@ struct PivotState {
 }  // namespace lpr
 
 struct lpr_tableau;
+struct lpr_revised;
 
 struct lpr_engine {
     int device = 0;
@@ -67,6 +68,7 @@ struct lpr_engine {
     // tableaux created on this engine and not yet destroyed; lpr_engine_close releases their
     // device memory and orphans them so that a late lpr_tableau_destroy stays safe
     std::vector<lpr_tableau*> live;
+    std::vector<lpr_revised*> live_rev;
 };
 
 struct lpr_tableau {

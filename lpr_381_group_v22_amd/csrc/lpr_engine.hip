@@ -34,6 +34,9 @@ void launch_build(lpr_tableau* t, int n, int m, const double* d_obj, const doubl
                   const int32_t* d_ncoef, const int8_t* d_rel, const double* d_rhs, int is_max);
 void launch_synthetic(lpr_tableau* t, int m, int n, uint64_t seed);
 
+// revised_engine.hip
+void rev_orphan(lpr_revised* s);
+
 enum : int { kSelEnter = 1, kSelLeave = 2, kSelCommit = 4, kSelFull = 7 };
 constexpr int kTimeStride = 4;  // opts.time_kernels samples one update launch in four
 
@@ -219,6 +222,8 @@ int lpr_engine_close(lpr_engine* e) {
         t->eng = nullptr;
     }
     e->live.clear();
+    for (lpr_revised* r : e->live_rev) rev_orphan(r);
+    e->live_rev.clear();
     if (e->stream) {
         hipStreamSynchronize(e->stream);
         hipStreamDestroy(e->stream);

@@ -1,0 +1,53 @@
+// revised_common.hpp -- device/host state of the revised primal simplex solver (internal).
+#pragma once
+
+#include "engine_common.hpp"
+
+namespace lpr {
+
+// Control block in device memory, polled by the host once per batch of iterations.
+struct RevState {
+    int32_t status;       // kRunning or an lpr_status
+    int32_t entering;     // entering variable chosen by k_rev_enter (-1: optimal)
+    int32_t leaving_row;  // basis row chosen by k_rev_ratio
+    int32_t pad;
+    int64_t iter;         // completed pivots
+    int64_t max_iter;     // stop when iter reaches this (<= 0: none)
+    int64_t log_cap;      // capacity of the (row, enter, leave) log in triples
+};
+
+}  // namespace lpr
+
+// RevisedPrimalSimplexSolver's fields (RevisedPrimalSimplexSolver.cs:15-33) in HBM.  `B` (:30) is
+// maintained by the C# but never read; it is not kept.
+struct lpr_revised {
+    lpr_engine* eng = nullptr;
+    int n = 0, m = 0;
+    int lda = 0, ldb = 0;       // leading dimensions of A (m x n) and B^-1 (m x m), 16-double padded
+    int is_min = 0;
+    double* A = nullptr;        // m x lda
+    double* Binv = nullptr;     // m x ldb
+    double* b = nullptr;        // m
+    double* c = nullptr;        // n   (= -cOrig for min, :51)
+    double* cOrig = nullptr;    // n
+    double* cB = nullptr;       // m
+    double* xB = nullptr;       // m
+    double* y = nullptr;        // m
+    double* rcx = nullptr;      // n
+    double* acol = nullptr;     // m   GetColumn(A, e)
+    double* u = nullptr;        // m   direction
+    double* fac = nullptr;      // m   column r of E (:272)
+    double* browbuf = nullptr;  // ldb old pivot row of B^-1
+    double* x = nullptr;        // n   SolutionVector
+    double* z = nullptr;        // 1   finalZ
+    int32_t* basic = nullptr;   // m   basicVariables (by row)
+    uint8_t* is_basic = nullptr;  // n + m: complement of nonBasicVariables
+    int32_t* log = nullptr;     // 3 * log_cap
+    int64_t log_cap = 0;
+    lpr::RevState* state = nullptr;
+    lpr::RevState* h_state = nullptr;  // pinned
+    double* gemm_out = nullptr;  // m x ldc scratch of lpr_revised_binv_a (lazy)
+    int ldc = 0;
+    int64_t total_iter = 0;
+    int last_status = 0;
+};

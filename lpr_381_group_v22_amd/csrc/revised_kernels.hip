@@ -1,0 +1,551 @@
+// revised_kernels.hip -- gfx950 kernels of the revised primal simplex
+// (reference: LPR_381_Group_V22/Simplex/RevisedPrimalSimplexSolver.cs).
+//
+// Every sum the C# forms is a sequential ascending-index loop `s += a * b` (product rounded, then
+// the add); the pivot decisions depend on those bits, so the kernels keep that order: one lane
+// owns one output element and walks its row / column serially, parallelism comes from the
+// independent outputs.  The two selections are the C#'s EPS-band sequential folds, evaluated
+// exactly by a "next take" search (see fold comments below).
+//
+//   k_rev_rowsum   MultiplyMatrixVector  :398-410   x_B = B^-1 b (:89), u = B^-1 a_e (:150)
+//   k_rev_colsum   MultiplyVectorMatrix  :412-424   y = c_B B^-1 (:93); rc_j = c_j - y.A_j (:96-98)
+//   k_rev_enter    feasibility (:90-91) + entering fold (:105-121)
+//   k_rev_gather   GetColumn(A, e) / GetColumn(BInverse, k) (:149-151, :390-396)
+//   k_rev_ratio    ratio-test fold (:154-176), bookkeeping (:194-212), eta factors (:266-272)
+//   k_rev_update   UpdateBInverse = E * B^-1 (:264-275 via MultiplyMatrices :426-441), in place
+//   k_rev_extract  ExtractSolution (:277-287)
+//   k_rev_gemm     MultiplyMatrices(BInverse, A) (:360) on fp64 MFMA (mfma_f64_16x16x4)
+#include "engine_common.hpp"
+#include "revised_common.hpp"
+
+#pragma clang fp contract(off)
+
+namespace lpr {
+
+constexpr double kEps = 1e-9;  // RevisedPrimalSimplexSolver.cs:12
+
+// ------------------------------------------------------------------------------------------
+// out[i] = sum_{j asc} M[i, j] * v[j], one lane per row, s starts at +0.0.
+// Rows are 128-byte aligned (ld % 16 == 0) so a lane reads its row 16 bytes at a time; 8 loads
+// are in flight per lane.  `skip_if_slack`: the u = B^-1 a_e launch is a no-op when the entering
+// variable is a slack (then u is a column of B^-1, written by k_rev_gather).
+__global__ __launch_bounds__(64) void k_rev_rowsum(const double* __restrict__ M, int ld, int m,
+                                                   const double* __restrict__ v,
+                                                   double* __restrict__ out,
+                                                   const RevState* __restrict__ st,
+                                                   int skip_if_slack, int n) {
+    if (st->status != kRunning) return;
+    if (skip_if_slack && st->entering >= n) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const double2* __restrict__ row = reinterpret_cast<const double2*>(M + (size_t)i * ld);
+    const int m2 = m >> 1;
+    double s = 0.0;
+    int k2 = 0;
+    for (; k2 + 8 <= m2; k2 += 8) {
+        double2 a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = row[k2 + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const double p0 = a[u].x * v[2 * (k2 + u)];
+            s = s + p0;
+            const double p1 = a[u].y * v[2 * (k2 + u) + 1];
+            s = s + p1;
+        }
+    }
+    for (; k2 < m2; ++k2) {
+        const double2 a = row[k2];
+        const double p0 = a.x * v[2 * k2];
+        s = s + p0;
+        const double p1 = a.y * v[2 * k2 + 1];
+        s = s + p1;
+    }
+    if (m & 1) {
+        const double p0 = M[(size_t)i * ld + (m - 1)] * v[m - 1];
+        s = s + p0;
+    }
+    out[i] = s;
+}
+
+// ------------------------------------------------------------------------------------------
+// s_j = sum_{i asc} v[i] * M[i, j], one lane per column (coalesced across lanes), s starts +0.0.
+//   mode 0: out[j] = s_j                (y = c_B B^-1)
+//   mode 1: out[j] = c[j] - s_j         (rc_j = c_j - Dot(y, GetColumn(A, j)), :98)
+// Dot(y, col) multiplies y[i] * col[i] -- the same operand order as v[i] * M[i, j]; IEEE
+// multiplication is commutative, so MultiplyVectorMatrix and Dot share this kernel.
+__global__ __launch_bounds__(64) void k_rev_colsum(const double* __restrict__ M, int ld, int rows,
+                                                   int cols, const double* __restrict__ v,
+                                                   const double* __restrict__ c,
+                                                   double* __restrict__ out, int mode,
+                                                   const RevState* __restrict__ st) {
+    if (st->status != kRunning) return;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= cols) return;
+    const double* __restrict__ col = M + j;
+    double s = 0.0;
+    int i = 0;
+    for (; i + 16 <= rows; i += 16) {
+        double a[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) a[u] = col[(size_t)(i + u) * ld];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const double p = v[i + u] * a[u];
+            s = s + p;
+        }
+    }
+    for (; i < rows; ++i) {
+        const double p = v[i] * col[(size_t)i * ld];
+        s = s + p;
+    }
+    out[j] = mode ? (c[j] - s) : s;
+}
+
+// ------------------------------------------------------------------------------------------
+// Block-wide minimum of an int (smallest index that satisfies a predicate; INT_MAX = none).
+__device__ __forceinline__ int block_min_int(int v, int* lds) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    const int nwaves = blockDim.x / kWave;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, kWave));
+    __syncthreads();
+    if (lane == 0) lds[wave] = v;
+    __syncthreads();
+    int r = lds[0];
+    for (int w = 1; w < nwaves; ++w) r = min(r, lds[w]);
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------
+// Entering variable, RevisedPrimalSimplexSolver.cs:105-121:
+//     foreach vIdx in nonBasic ascending:  rc > EPS  and
+//         (none yet  or  rc > best + EPS  or  (|rc - best| <= EPS and vIdx < enteringIdx))  -> take
+// The third clause can never fire while indices are visited in ascending order.  The comparator is
+// an EPS-band rule and not associative, so it is not reduced as a tree: the fold is replayed
+// exactly by repeatedly searching, in parallel, for the FIRST index after the current one at
+// which the C# would replace its running best ("next take"), until there is none.  The number of
+// rounds is the number of replacements the sequential loop makes (O(log N) on random data).
+// Also performs the feasibility test `xB.Any(x => x < -EPS)` (:90-91) and the pivot-limit check.
+__global__ __launch_bounds__(1024) void k_rev_enter(const double* __restrict__ rcx,
+                                                    const double* __restrict__ y,
+                                                    const double* __restrict__ xB,
+                                                    const uint8_t* __restrict__ is_basic, int n,
+                                                    int m, RevState* st) {
+    __shared__ int lds[16];
+    if (st->status != kRunning) return;
+    const int tid = threadIdx.x;
+    const int nt = blockDim.x;
+
+    int bad = INT_MAX;
+    for (int i = tid; i < m; i += nt)
+        if (xB[i] < -kEps) { bad = i; break; }
+    bad = block_min_int(bad, lds);
+    if (bad != INT_MAX) {
+        if (tid == 0) st->status = LPR_INFEASIBLE_BASIS;
+        return;
+    }
+
+    const int N = n + m;
+    int cur = -1;          // enteringIdx
+    double best = -INFINITY;  // bestPosRC
+    for (;;) {
+        int first = INT_MAX;
+        for (int k = tid; k < N; k += nt) {
+            if (k <= cur || is_basic[k]) continue;
+            const double rc = (k < n) ? rcx[k] : -y[k - n];  // rcS_k = -y_k (:100-102)
+            if (rc > kEps && (cur == -1 || rc > best + kEps)) {
+                first = k;
+                break;  // this lane's indices ascend: its first hit is its smallest
+            }
+        }
+        first = block_min_int(first, lds);
+        if (first == INT_MAX) break;
+        cur = first;
+        best = (cur < n) ? rcx[cur] : -y[cur - n];
+    }
+    if (tid == 0) {
+        st->entering = cur;
+        if (cur < 0) st->status = LPR_OK_OPTIMAL;  // :124-146
+        else if (st->max_iter > 0 && st->iter >= st->max_iter) st->status = LPR_PIVOT_LIMIT;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// GetColumn (:390-396): structural e -> acol = A[:, e] (input of u = B^-1 a_e);
+// slack e = n + k -> u = BInverse[:, k] directly (:151).
+__global__ __launch_bounds__(256) void k_rev_gather(const double* __restrict__ A, int lda,
+                                                    const double* __restrict__ Binv, int ldb,
+                                                    int n, int m, double* __restrict__ acol,
+                                                    double* __restrict__ u,
+                                                    const RevState* __restrict__ st) {
+    if (st->status != kRunning) return;
+    const int e = st->entering;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    if (e < n) acol[i] = A[(size_t)i * lda + e];
+    else u[i] = Binv[(size_t)i * ldb + (e - n)];
+}
+
+// ------------------------------------------------------------------------------------------
+// Ratio test, RevisedPrimalSimplexSolver.cs:154-176:
+//     for i ascending, u_i > EPS, ratio = xB_i / u_i:
+//         ratio < best - EPS  or  (|ratio - best| <= EPS and (none yet or basic[i] < basic[row]))
+// `best` may move UP by up to EPS on a band take, so no prefix-minimum shortcut is valid; the
+// same exact "next take" replay as k_rev_enter is used.  Then the bookkeeping of :181-212 and the
+// column of the elementary matrix E (:266-272): fac[r] = 1/p, fac[i] = -u_i / p.  The old pivot
+// row of B^-1 is copied to browbuf because k_rev_update works in place.
+__global__ __launch_bounds__(1024) void k_rev_ratio(const double* __restrict__ u,
+                                                    const double* __restrict__ xB,
+                                                    int32_t* __restrict__ basic,
+                                                    uint8_t* __restrict__ is_basic,
+                                                    double* __restrict__ cB,
+                                                    const double* __restrict__ c,
+                                                    const double* __restrict__ Binv, int ldb,
+                                                    double* __restrict__ browbuf,
+                                                    double* __restrict__ fac,
+                                                    int32_t* __restrict__ log, int n, int m,
+                                                    RevState* st) {
+    __shared__ int lds[16];
+    if (st->status != kRunning) return;
+    const int tid = threadIdx.x;
+    const int nt = blockDim.x;
+    const int e = st->entering;
+
+    int row = -1;           // leavingRow
+    double best = DBL_MAX;  // bestRatio
+    int cur = -1;           // last index examined by the replayed loop
+    for (;;) {
+        const int brow = (row >= 0) ? basic[row] : 0;
+        int first = INT_MAX;
+        for (int i = tid; i < m; i += nt) {
+            if (i <= cur) continue;
+            const double ui = u[i];
+            if (!(ui > kEps)) continue;
+            const double ratio = xB[i] / ui;
+            if (ratio < best - kEps ||
+                (fabs(ratio - best) <= kEps && (row == -1 || basic[i] < brow))) {
+                first = i;
+                break;
+            }
+        }
+        first = block_min_int(first, lds);
+        if (first == INT_MAX) break;
+        cur = first;
+        row = first;
+        best = xB[first] / u[first];
+    }
+    if (row < 0) {
+        if (tid == 0) st->status = LPR_UNBOUNDED;  // :178-179
+        return;
+    }
+    const int leavingVar = basic[row];
+    if (leavingVar == e) {
+        if (tid == 0) st->status = LPR_ENTERING_ALREADY_BASIC;  // :182-183
+        return;
+    }
+    const double pivot = u[row];
+    __syncthreads();  // every lane has read basic[row] before it is overwritten
+    if (tid == 0) {
+        const int64_t it = st->iter;
+        if (it < st->log_cap) {
+            log[3 * it] = row;
+            log[3 * it + 1] = e;
+            log[3 * it + 2] = leavingVar;
+        }
+        basic[row] = e;               // :195
+        is_basic[e] = 1;              // nonBasic.Remove(entering) :196
+        is_basic[leavingVar] = 0;     // nonBasic.Add(leavingVar)  :197-198
+        cB[row] = (e < n) ? c[e] : 0.0;  // :205,211
+        st->leaving_row = row;
+        if (fabs(pivot) < kEps) st->status = LPR_PIVOT_TOO_SMALL;  // :267 (after the bookkeeping)
+        else st->iter = it + 1;  // :249
+    }
+    if (fabs(pivot) < kEps) return;
+    for (int i = tid; i < m; i += nt) {
+        fac[i] = (i == row) ? 1.0 / pivot : -u[i] / pivot;  // :272
+        browbuf[i] = Binv[(size_t)row * ldb + i];
+    }
+    for (int i = m + tid; i < ldb; i += nt) browbuf[i] = 0.0;
+}
+
+// ------------------------------------------------------------------------------------------
+// UpdateBInverse (:264-275): BInverse = MultiplyMatrices(E, BInverse), E = I with column r
+// replaced by fac.  MultiplyMatrices (:426-441) starts every R[i,j] at +0.0 and adds the terms of
+// the non-skipped k in ascending order, so for row i the result is
+//     i <  r : (0.0 + 1.0*B[i,j]) + fac_i*B[r,j]        (second term skipped if |fac_i| < EPS)
+//     i >  r : (0.0 + fac_i*B[r,j]) + 1.0*B[i,j]        (first term skipped if |fac_i| < EPS)
+//     i == r :  0.0 + fac_r*B[r,j]                      (0.0 if |fac_r| < EPS)
+// Same streaming shape as the tableau update: 16 B/lane, pivot-row slice in registers.
+template <int TR>
+__global__ __launch_bounds__(256) void k_rev_update(double* __restrict__ Binv, int ld, int m,
+                                                    const double* __restrict__ browbuf,
+                                                    const double* __restrict__ fac,
+                                                    const RevState* __restrict__ st) {
+    if (st->status != kRunning) return;
+    const int r = st->leaving_row;
+    const int ld2 = ld >> 1;
+    const int c2 = blockIdx.x * 256 + threadIdx.x;
+    if (c2 >= ld2) return;
+    const double2 br = reinterpret_cast<const double2*>(browbuf)[c2];
+    double2* __restrict__ B2 = reinterpret_cast<double2*>(Binv);
+    const int i0 = blockIdx.y * TR;
+    double2 x[TR];
+#pragma unroll
+    for (int k = 0; k < TR; ++k)
+        if (i0 + k < m) x[k] = B2[(size_t)(i0 + k) * ld2 + c2];
+#pragma unroll
+    for (int k = 0; k < TR; ++k) {
+        const int i = i0 + k;
+        if (i < m) {
+            const double f = fac[i];
+            const bool use = !(fabs(f) < kEps);
+            const double px = f * br.x;
+            const double py = f * br.y;
+            double2 o;
+            if (i == r) {
+                o.x = use ? 0.0 + px : 0.0;
+                o.y = use ? 0.0 + py : 0.0;
+            } else if (i < r) {
+                const double tx = 0.0 + x[k].x;  // 1.0 * B[i,j] is exact
+                const double ty = 0.0 + x[k].y;
+                o.x = use ? tx + px : tx;
+                o.y = use ? ty + py : ty;
+            } else {
+                const double tx = use ? 0.0 + px : 0.0;
+                const double ty = use ? 0.0 + py : 0.0;
+                o.x = tx + x[k].x;
+                o.y = ty + x[k].y;
+            }
+            // padding columns (j >= m) stay 0: browbuf is 0 there and x is 0
+            B2[(size_t)i * ld2 + c2] = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// ExtractSolution (:277-287): x[basic[i]] = Math.Max(0.0, xB[i]) for structural basics,
+// finalZ = Dot(cOrig, x) -- a sequential sum, done by one lane.
+__global__ __launch_bounds__(256) void k_rev_extract(const int32_t* __restrict__ basic,
+                                                     const double* __restrict__ xB,
+                                                     const double* __restrict__ cOrig, int n,
+                                                     int m, double* __restrict__ x,
+                                                     double* __restrict__ z) {
+    const int tid = threadIdx.x;
+    for (int j = tid; j < n; j += blockDim.x) x[j] = 0.0;
+    __syncthreads();
+    for (int i = tid; i < m; i += blockDim.x) {
+        const int v = basic[i];
+        if (v < n) {
+            const double xb = xB[i];
+            x[v] = (0.0 > xb) ? 0.0 : xb;  // .NET Framework Math.Max(0.0, xb)
+        }
+    }
+    __syncthreads();
+    __threadfence_block();
+    if (tid == 0) {
+        double s = 0.0;
+        for (int j = 0; j < n; ++j) {
+            const double p = cOrig[j] * x[j];
+            s = s + p;
+        }
+        *z = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Synthetic dense LP for the benchmark (same generator as the tableau form).
+__device__ __forceinline__ uint64_t rsplitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ULL;
+    uint64_t z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ double ru01(uint64_t seed, uint64_t stream, uint64_t i, uint64_t j) {
+    uint64_t k = rsplitmix64(seed ^ (stream * 0xD1B54A32D192ED03ULL));
+    k = rsplitmix64(k + i);
+    k = rsplitmix64(k + j);
+    return (double)(k >> 11) * 0x1.0p-53;
+}
+
+__global__ __launch_bounds__(256) void k_rev_synthetic(double* __restrict__ A, int lda, int m,
+                                                       int n, uint64_t seed,
+                                                       double* __restrict__ b,
+                                                       double* __restrict__ c,
+                                                       double* __restrict__ cOrig) {
+    const int i = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < lda) A[(size_t)i * lda + j] = (j < n) ? ru01(seed, 0, (uint64_t)i, (uint64_t)j) : 0.0;
+    if (j == 0) {
+        const double u = ru01(seed, 1, (uint64_t)i, 0);
+        const double s = u * 0.1;
+        const double t = 1.0 + s;
+        b[i] = ((double)n * 0.25) * t;
+    }
+    if (i == 0 && j < n) {
+        const double v = ru01(seed, 2, 0, (uint64_t)j);
+        c[j] = v;
+        cOrig[j] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_rev_init(double* __restrict__ Binv, int ldb, int m, int n,
+                                                  int32_t* __restrict__ basic,
+                                                  uint8_t* __restrict__ is_basic) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // :72-79
+    if (i < m) {
+        Binv[(size_t)i * ldb + i] = 1.0;
+        basic[i] = n + i;
+    }
+    if (i < n + m) is_basic[i] = (i >= n) ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// B^-1 * A on the matrix cores:  C[m x n] = Bz[m x m] * A[m x n],  Bz = B^-1 with the entries the
+// C# skips (|b_ik| < 1e-9, MultiplyMatrices :436) replaced by 0.  fp64 MFMA 16x16x4
+// (v_mfma_f64_16x16x4_f64): per wave-instruction A-operand lane l holds Bz[i = l & 15][k = l >> 4],
+// B-operand lane l holds A[k = l >> 4][j = l & 15], the 16x16 result has 4 f64 per lane at
+// col = l & 15, row = (l >> 4) + 4 * reg  (cdna_hip_programming.md section 3, f64 map).
+// Block = 256 threads = 4 waves, block tile 128 x 128, each wave 64 x 64 = 4 x 4 MFMA tiles,
+// K stepped by 16 through LDS (double-buffered).  The sum over k is formed per 4-wide MFMA step
+// with FMA accumulation, i.e. NOT the C#'s rounded-product sequential sum: this product feeds only
+// the printed snapshot tableau (3 decimals), so its parity bar is a tolerance, not bits.
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+constexpr int GM = 128, GN = 128, GK = 16;
+constexpr int LDA_S = GK + 1;   // Bz tile stored [row][k], padded: the A-operand read walks rows
+constexpr int LDB_S = GN + 16;  // A tile stored [k][col]; +16 doubles = 32 banks: k and k+1 rows
+                                // of one ds_read_b64 land on disjoint bank halves
+
+__global__ __launch_bounds__(256) void k_rev_gemm(const double* __restrict__ Binv, int ldb,
+                                                  const double* __restrict__ A, int lda,
+                                                  double* __restrict__ Cout, int ldc, int m,
+                                                  int n) {
+    __shared__ double sA[2][GM * LDA_S];
+    __shared__ double sB[2][GK * LDB_S];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = (wave >> 1) * 64;  // wave tile origin inside the block tile
+    const int wn = (wave & 1) * 64;
+    const int bm = blockIdx.y * GM;
+    const int bn = blockIdx.x * GN;
+
+    double4_t acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+
+    // global -> LDS staging maps: Bz tile 128 x 16 (2048 doubles, 8 per thread), A tile 16 x 128
+    auto stage = [&](int buf, int k0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int idx = tid + q * 256;  // 0..2047
+            const int r = idx >> 4, kk = idx & 15;
+            const int gi = bm + r, gk = k0 + kk;
+            double v = (gi < m && gk < m) ? Binv[(size_t)gi * ldb + gk] : 0.0;
+            if (fabs(v) < kEps) v = 0.0;  // :436 zero-skip
+            sA[buf][r * LDA_S + kk] = v;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int idx = tid + q * 256;
+            const int kk = idx >> 7, cidx = idx & 127;
+            const int gk = k0 + kk, gj = bn + cidx;
+            sB[buf][kk * LDB_S + cidx] = (gk < m && gj < n) ? A[(size_t)gk * lda + gj] : 0.0;
+        }
+    };
+
+    const int nk = (m + GK - 1) / GK;
+    stage(0, 0);
+    __syncthreads();
+    for (int t = 0; t < nk; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nk) stage(buf ^ 1, (t + 1) * GK);
+#pragma unroll
+        for (int ks = 0; ks < GK; ks += 4) {
+            double af[4], bf[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+                af[a] = sA[buf][(wm + a * 16 + (lane & 15)) * LDA_S + ks + (lane >> 4)];
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                bf[b] = sB[buf][(ks + (lane >> 4)) * LDB_S + wn + b * 16 + (lane & 15)];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0,
+                                                                     0, 0);
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int gi = bm + wm + a * 16 + (lane >> 4) + 4 * rg;
+                const int gj = bn + wn + b * 16 + (lane & 15);
+                if (gi < m && gj < n) Cout[(size_t)gi * ldc + gj] = acc[a][b][rg];
+            }
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+
+void rev_launch_iteration(lpr_revised* s) {
+    hipStream_t st = s->eng->stream;
+    const int m = s->m, n = s->n;
+    // x_B = B^-1 b (:89)
+    hipLaunchKernelGGL(k_rev_rowsum, dim3((m + 63) / 64), dim3(64), 0, st, s->Binv, s->ldb, m,
+                       s->b, s->xB, s->state, 0, n);
+    // y = c_B B^-1 (:93)
+    hipLaunchKernelGGL(k_rev_colsum, dim3((m + 63) / 64), dim3(64), 0, st, s->Binv, s->ldb, m, m,
+                       s->cB, (const double*)nullptr, s->y, 0, s->state);
+    // rc_j = c_j - y.A_j (:96-98)
+    hipLaunchKernelGGL(k_rev_colsum, dim3((n + 63) / 64), dim3(64), 0, st, s->A, s->lda, m, n,
+                       s->y, s->c, s->rcx, 1, s->state);
+    hipLaunchKernelGGL(k_rev_enter, dim3(1), dim3(1024), 0, st, s->rcx, s->y, s->xB, s->is_basic,
+                       n, m, s->state);
+    hipLaunchKernelGGL(k_rev_gather, dim3((m + 255) / 256), dim3(256), 0, st, s->A, s->lda,
+                       s->Binv, s->ldb, n, m, s->acol, s->u, s->state);
+    // u = B^-1 a_e (:150) unless the entering variable is a slack
+    hipLaunchKernelGGL(k_rev_rowsum, dim3((m + 63) / 64), dim3(64), 0, st, s->Binv, s->ldb, m,
+                       s->acol, s->u, s->state, 1, n);
+    hipLaunchKernelGGL(k_rev_ratio, dim3(1), dim3(1024), 0, st, s->u, s->xB, s->basic,
+                       s->is_basic, s->cB, s->c, s->Binv, s->ldb, s->browbuf, s->fac, s->log, n, m,
+                       s->state);
+    constexpr int TR = 8;
+    hipLaunchKernelGGL((k_rev_update<TR>), dim3((s->ldb / 2 + 255) / 256, (m + TR - 1) / TR),
+                       dim3(256), 0, st, s->Binv, s->ldb, m, s->browbuf, s->fac, s->state);
+}
+
+void rev_launch_extract(lpr_revised* s) {
+    hipLaunchKernelGGL(k_rev_extract, dim3(1), dim3(256), 0, s->eng->stream, s->basic, s->xB,
+                       s->cOrig, s->n, s->m, s->x, s->z);
+}
+
+void rev_launch_init(lpr_revised* s) {
+    const int tot = s->n + s->m;
+    hipLaunchKernelGGL(k_rev_init, dim3((tot + 255) / 256), dim3(256), 0, s->eng->stream, s->Binv,
+                       s->ldb, s->m, s->n, s->basic, s->is_basic);
+}
+
+void rev_launch_synthetic(lpr_revised* s, uint64_t seed) {
+    hipLaunchKernelGGL(k_rev_synthetic, dim3((s->lda + 255) / 256, s->m), dim3(256), 0,
+                       s->eng->stream, s->A, s->lda, s->m, s->n, seed, s->b, s->c, s->cOrig);
+}
+
+void rev_launch_gemm(lpr_revised* s, double* Cout, int ldc) {
+    dim3 grid((s->n + GN - 1) / GN, (s->m + GM - 1) / GM);
+    hipLaunchKernelGGL(k_rev_gemm, grid, dim3(256), 0, s->eng->stream, s->Binv, s->ldb, s->A,
+                       s->lda, Cout, ldc, s->m, s->n);
+}
+
+}  // namespace lpr

@@ -180,3 +180,90 @@ class Tableau:
         N.check(N.lib.lpr_tableau_kernel_stats(self._h, C.byref(n), C.byref(tot), C.byref(avg)),
                 "lpr_tableau_kernel_stats")
         return n.value, tot.value, avg.value
+
+
+class RevisedState:
+    """Device-resident state of the revised primal simplex (lpr_revised_*)."""
+
+    def __init__(self, engine: Engine, handle: C.c_void_p, n: int, m: int):
+        self.engine = engine
+        self._h = handle
+        self.n, self.m = n, m
+
+    @classmethod
+    def create(cls, engine: Engine, objective: Sequence[float], A: np.ndarray,
+               b: Sequence[float], is_min: bool) -> "RevisedState":
+        obj = np.ascontiguousarray(objective, dtype=np.float64)
+        bb = np.ascontiguousarray(b, dtype=np.float64)
+        n, m = obj.shape[0], bb.shape[0]
+        A = np.ascontiguousarray(A, dtype=np.float64).reshape(m, n) if m and n else \
+            np.zeros((max(m, 1), max(n, 1)))
+        h = C.c_void_p()
+        N.check(N.lib.lpr_revised_create(engine._h, n, m, _dptr(obj), _dptr(A), max(n, 1),
+                                         _dptr(bb), 1 if is_min else 0, C.byref(h)),
+                "lpr_revised_create")
+        return cls(engine, h, n, m)
+
+    @classmethod
+    def synthetic(cls, engine: Engine, m: int, n: int, seed: int) -> "RevisedState":
+        h = C.c_void_p()
+        N.check(N.lib.lpr_revised_synthetic(engine._h, m, n, C.c_uint64(seed), C.byref(h)),
+                "lpr_revised_synthetic")
+        return cls(engine, h, n, m)
+
+    def destroy(self):
+        if self._h:
+            N.lib.lpr_revised_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+    def solve(self, max_pivots: int = 0, batch: int = 0) -> N.RevisedResult:
+        opts = N.SolveOpts(max_pivots=max_pivots, time_kernels=0, batch=batch, variant=0,
+                           reserved=0)
+        res = N.RevisedResult()
+        N.check(N.lib.lpr_revised_solve(self._h, C.byref(opts), C.byref(res)),
+                "lpr_revised_solve")
+        return res
+
+    def solution(self) -> Tuple[np.ndarray, float]:
+        x = np.zeros(self.n, dtype=np.float64)
+        z = C.c_double()
+        N.check(N.lib.lpr_revised_solution(self._h, _dptr(x), C.byref(z)), "lpr_revised_solution")
+        return x, z.value
+
+    def basis(self) -> np.ndarray:
+        out = np.zeros(self.m, dtype=np.int32)
+        N.check(N.lib.lpr_revised_basis_read(self._h, _i32ptr(out)), "lpr_revised_basis_read")
+        return out
+
+    def log(self, cap: int = 1 << 20) -> np.ndarray:
+        r = np.zeros(cap, dtype=np.int32)
+        e = np.zeros(cap, dtype=np.int32)
+        lv = np.zeros(cap, dtype=np.int32)
+        cnt = C.c_int64()
+        N.check(N.lib.lpr_revised_log_read(self._h, _i32ptr(r), _i32ptr(e), _i32ptr(lv), cap,
+                                           C.byref(cnt)), "lpr_revised_log_read")
+        k = cnt.value
+        return np.stack([r[:k], e[:k], lv[:k]], axis=1)
+
+    def binv(self) -> np.ndarray:
+        out = np.empty((self.m, self.m), dtype=np.float64)
+        N.check(N.lib.lpr_revised_binv_read(self._h, _dptr(out)), "lpr_revised_binv_read")
+        return out
+
+    def xb(self) -> np.ndarray:
+        out = np.empty(self.m, dtype=np.float64)
+        N.check(N.lib.lpr_revised_xb_read(self._h, _dptr(out)), "lpr_revised_xb_read")
+        return out
+
+    def binv_a(self, fetch: bool = True) -> Tuple[Optional[np.ndarray], float]:
+        """B^-1 * A on the fp64 matrix cores; returns (product or None, kernel milliseconds)."""
+        out = np.empty((self.m, self.n), dtype=np.float64) if fetch else None
+        ms = C.c_double()
+        N.check(N.lib.lpr_revised_binv_a(self._h, _dptr(out), C.byref(ms)), "lpr_revised_binv_a")
+        return out, ms.value

@@ -1,0 +1,183 @@
+"""GPU parity tests of the revised primal simplex (lpr_revised_*) against the CPU oracle.
+Bar: identical status / pivot log / basis, bit-exact B^-1, x_B, x and Z (all sums keep the C#'s
+sequential order on the device); tolerance only for the MFMA product B^-1 * A."""
+import struct
+
+import numpy as np
+import pytest
+
+import lp_cases
+from test_oracle_revised import flat, revised_cases
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(x):
+    return struct.pack(">d", float(x)).hex()
+
+
+def to_constraints(cons):
+    from lpr_381_group_v22_amd import Constraint
+    return [Constraint(list(c.Coefficients), c.Relation, c.RHS) for c in cons]
+
+
+@pytest.mark.parametrize("name,case", revised_cases(), ids=[c[0] for c in revised_cases()])
+def test_solver_mirror_matches_oracle(engine, oracle, name, case):
+    from lpr_381_group_v22_amd import RevisedPrimalSimplexSolver, SolverException
+    obj, cons, is_min = case
+    A, b = flat(cons)
+    ref = oracle.revised_solve(obj, A, b, is_min, max_iter=3000)
+    s = RevisedPrimalSimplexSolver(obj, to_constraints(cons), is_min, engine=engine)
+    raised = None
+    try:
+        s.Solve(max_pivots=3000)
+    except SolverException as ex:
+        raised = ex
+    assert s.Status == ref["status"]
+    if ref["status"] in (1, 2, 3, 4):  # the C# throws (:91, :179, :183, :267)
+        assert raised is not None and raised.status == ref["status"]
+    else:
+        assert raised is None
+    assert s.PivotLog.tolist() == ref["log"].tolist()
+    assert s.BasicVariables == ref["basis"].tolist()
+    assert s.state.binv().tobytes() == ref["Binv"].tobytes(), "B^-1 not bit-identical"
+    assert s.state.xb().tobytes() == ref["xB"].tobytes(), "x_B not bit-identical"
+    if ref["status"] == 0:
+        assert bits(s.FinalZ) == bits(ref["z"])
+        assert [bits(v) for v in s.SolutionVector] == [bits(v) for v in ref["x"]]
+
+
+def test_sample_model_option2(engine):
+    """data/TextFile.txt through Program.cs option 2."""
+    from lpr_381_group_v22_amd import RevisedPrimalSimplexSolver
+    from test_oracle_revised import sample_option2
+    obj, cons, is_min = sample_option2()
+    s = RevisedPrimalSimplexSolver(obj, to_constraints(cons), is_min, engine=engine)
+    s.Solve()
+    assert bits(s.FinalZ) == bits(15.399999999999999)
+    assert bits(s.SolutionVector[4]) == bits(0.19999999999999973)
+    assert s.PivotLog.tolist() == [[4, 3, 10], [6, 5, 12], [2, 1, 8], [3, 2, 9], [0, 0, 6],
+                                   [0, 4, 0]]
+
+
+def test_constructor_argument_errors(engine):
+    from lpr_381_group_v22_amd import Constraint, RevisedPrimalSimplexSolver
+    with pytest.raises(ValueError, match="Objective cannot be null or empty"):
+        RevisedPrimalSimplexSolver([], [Constraint([1.0], "<=", 1.0)], False, engine=engine)
+    with pytest.raises(ValueError, match="Constraints cannot be null or empty"):
+        RevisedPrimalSimplexSolver([1.0], [], False, engine=engine)
+    with pytest.raises(ValueError, match="Constraint 2 has incorrect number of coefficients"):
+        RevisedPrimalSimplexSolver([1.0, 2.0], [Constraint([1.0, 1.0], "<=", 1.0),
+                                                Constraint([1.0], "<=", 1.0)], False,
+                                   engine=engine)
+
+
+@pytest.mark.parametrize("m,n,seed", [(64, 128, 0), (200, 333, 1), (257, 100, 2)])
+def test_synthetic_lp_full_solve(engine, oracle, m, n, seed):
+    from lpr_381_group_v22_amd import RevisedState
+    c, A, b = oracle.gen_dense_lp(m, n, seed)
+    ref = oracle.revised_solve(c, A, b, False, max_iter=20000)
+    st = RevisedState.synthetic(engine, m, n, seed)
+    res = st.solve(max_pivots=20000)
+    assert res.status == ref["status"] == 0
+    assert res.iterations == ref["iterations"]
+    assert st.log().tolist() == ref["log"].tolist()
+    assert st.basis().tolist() == ref["basis"].tolist()
+    assert st.binv().tobytes() == ref["Binv"].tobytes()
+    x, z = st.solution()
+    assert x.tobytes() == ref["x"].tobytes() and bits(z) == bits(ref["z"]) == bits(res.z)
+    st.destroy()
+
+
+def test_resume_after_limit(engine, oracle):
+    from lpr_381_group_v22_amd import RevisedState
+    m, n, seed = 40, 80, 3
+    c, A, b = oracle.gen_dense_lp(m, n, seed)
+    ref = oracle.revised_solve(c, A, b, False)
+    st = RevisedState.synthetic(engine, m, n, seed)
+    total = 0
+    while True:
+        res = st.solve(max_pivots=5, batch=2)
+        total += res.iterations
+        if res.status != 5:
+            break
+        assert res.iterations == 5
+    assert res.status == 0 and total == ref["iterations"]
+    assert st.log().tolist() == ref["log"].tolist()
+    assert st.binv().tobytes() == ref["Binv"].tobytes()
+    st.destroy()
+
+
+def test_update_binverse_zero_skip_and_negative_zero(engine, oracle):
+    """UpdateBInverse goes through MultiplyMatrices' `|a_ik| < EPS -> continue` (:436): rows whose
+    eta factor is below 1e-9 keep their values (with -0 -> +0), and 1/p below 1e-9 zeroes the
+    pivot row.  Degenerate integer LPs hit the first rule; the tie-heavy family covers it."""
+    from lpr_381_group_v22_amd import RevisedPrimalSimplexSolver
+    for seed in range(5):
+        obj, cons, _ = lp_cases.tie_heavy(20, 16, 100 + seed)
+        A, b = flat(cons)
+        b = np.abs(b)  # keep the slack basis feasible so that the solve runs
+        cons = [type(c)(c.Coefficients, c.Relation, float(bb)) for c, bb in zip(cons, b)]
+        ref = oracle.revised_solve(obj, A, b, False, max_iter=500)
+        s = RevisedPrimalSimplexSolver(obj, to_constraints(cons), False, engine=engine)
+        try:
+            s.Solve(max_pivots=500)
+        except Exception:
+            pass
+        assert s.Status == ref["status"]
+        assert s.PivotLog.tolist() == ref["log"].tolist()
+        assert s.state.binv().tobytes() == ref["Binv"].tobytes()
+
+
+@pytest.mark.parametrize("m,n,seed,iters", [(96, 200, 0, 40), (130, 70, 1, 25), (300, 517, 2, 100)])
+def test_binv_a_mfma_product(engine, oracle, m, n, seed, iters):
+    """B^-1 * A (CaptureSnapshot :360) on the fp64 matrix cores vs the oracle's literal i-k-j loop
+    with zero-skip.  Tolerance (stated): |err| <= 1e-9 * (|B^-1| |A|)_ij + 1e-12 -- the MFMA path
+    accumulates with FMAs in a different association than the C#; the product only feeds the 3-dp
+    printed tableau."""
+    from lpr_381_group_v22_amd import RevisedState
+    c, A, b = oracle.gen_dense_lp(m, n, seed)
+    st = RevisedState.synthetic(engine, m, n, seed)
+    res = st.solve(max_pivots=iters)
+    Binv = st.binv()
+    want = oracle.matmul_skip(Binv, A)
+    got, ms = st.binv_a()
+    assert ms > 0
+    bound = 1e-9 * (np.abs(Binv) @ np.abs(A)) + 1e-12
+    assert (np.abs(got - want) <= bound).all(), float(np.abs(got - want).max())
+    # structure: the columns of basic structural variables are unit vectors of B^-1 A
+    basis = st.basis()
+    for row, v in enumerate(basis):
+        if v < n:
+            col = got[:, v]
+            e = np.zeros(m)
+            e[row] = 1.0
+            assert np.abs(col - e).max() < 1e-7
+    st.destroy()
+
+
+def test_binv_a_zero_skip_is_applied(engine, oracle):
+    """Entries of B^-1 below 1e-9 must not contribute (MultiplyMatrices :436).  Badly scaled
+    coefficients leave such entries in B^-1 after a few pivots; with columns of A as large as 1e6
+    a product that ignored the skip would miss the stated tolerance."""
+    from lpr_381_group_v22_amd import RevisedState
+    m, n = 32, 48
+    rng = np.random.RandomState(0)
+    A = 10.0 ** rng.uniform(-6, 6, size=(m, n))
+    b = 10.0 ** rng.uniform(0, 3, size=m)
+    c = rng.rand(n)
+    st = RevisedState.create(engine, c, A, b, False)
+    got, _ = st.binv_a()
+    assert got.tobytes() == oracle.matmul_skip(np.eye(m), A).tobytes()  # I * A is exact
+    ref = oracle.revised_solve(c, A, b, False, max_iter=12)
+    st.solve(max_pivots=12)
+    Binv = st.binv()
+    assert Binv.tobytes() == ref["Binv"].tobytes()
+    tiny = (np.abs(Binv) < 1e-9) & (Binv != 0.0)
+    assert tiny.any(), "fixture no longer produces sub-EPS entries in B^-1"
+    want = oracle.matmul_skip(Binv, A)
+    got, _ = st.binv_a()
+    Bz = np.where(np.abs(Binv) < 1e-9, 0.0, Binv)
+    bound = 1e-9 * (np.abs(Bz) @ np.abs(A)) + 1e-12
+    assert (np.abs(got - want) <= bound).all()
+    st.destroy()
