@@ -71,6 +71,23 @@ int orc_revised_solve(int n, int m, const double* objective, const double* A, co
                       double* Binv_out, double* xB_out, int32_t* log_row, int32_t* log_enter,
                       int32_t* log_leave, int64_t log_cap, int64_t* iterations);
 
+/* ---- Branch & Bound (IntegerProgramming/BranchBoundSimplexSolver.cs, BranchAndBoundAdapter.cs) ---- */
+double orc_round_int(double x); /* .NET Framework Math.Round(double)     */
+double orc_round4(double x);    /* .NET Framework Math.Round(double, 4)  */
+/* BranchAndBoundAdapter.SolveFromPrimal + ExecuteBranchAndBound; see oracle_bb.c for the outputs */
+int orc_bb_solve(const double* final_tableau, int rows, int cols, int nvars, int enable_pruning,
+                 int node_cap, double* x, double* z, int* found, int* best_node,
+                 int* processed, int32_t* rec_parent, int32_t* rec_kind, int32_t* rec_depth,
+                 int32_t* rec_var, double* rec_bound, int32_t* rec_status, double* rec_z,
+                 int node_rec_cap, int* n_records, int32_t* pop_order, int32_t* piv_trace,
+                 int64_t piv_cap, int64_t* n_piv);
+/* AddConstraint :694-803 for one constraint (coefficients..., bound, type); out is (rows+1)x(cols+1) */
+int orc_bb_add_constraint(const double* base, int rows, int cols, const double* con, int conLen,
+                          double* out);
+/* DoDualSimplex :289-468 (tableauOverride mode): 0 solved, 1 infeasible, 2 exception escaped */
+int orc_bb_dual_simplex(const double* start, int rows, int cols, double* out, int* npiv,
+                        int32_t* piv_trace, int64_t piv_cap, int64_t* n_piv);
+
 #ifdef __cplusplus
 }
 #endif

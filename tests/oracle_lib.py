@@ -71,6 +71,76 @@ class Oracle:
         lib.orc_revised_solve.argtypes = [C.c_int, C.c_int, _D, _D, _D, C.c_int, C.c_int64, _D,
                                           _D, _I32, _D, _D, _I32, _I32, _I32, C.c_int64, _I64]
 
+        lib.orc_round4.restype = C.c_double
+        lib.orc_round4.argtypes = [C.c_double]
+        lib.orc_round_int.restype = C.c_double
+        lib.orc_round_int.argtypes = [C.c_double]
+        _IP = C.POINTER(C.c_int)
+        lib.orc_bb_solve.restype = C.c_int
+        lib.orc_bb_solve.argtypes = [_D, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _D, _D, _IP,
+                                     _IP, _IP, _I32, _I32, _I32, _I32, _D, _I32, _D, C.c_int, _IP,
+                                     _I32, _I32, C.c_int64, _I64]
+        lib.orc_bb_add_constraint.restype = C.c_int
+        lib.orc_bb_add_constraint.argtypes = [_D, C.c_int, C.c_int, _D, C.c_int, _D]
+        lib.orc_bb_dual_simplex.restype = C.c_int
+        lib.orc_bb_dual_simplex.argtypes = [_D, C.c_int, C.c_int, _D, _IP, _I32, C.c_int64, _I64]
+
+    # ---- branch & bound ----
+    def round4(self, x):
+        return self.lib.orc_round4(x)
+
+    def round_int(self, x):
+        return self.lib.orc_round_int(x)
+
+    def bb_solve(self, final_tableau, nvars, enable_pruning=False, node_cap=20, rec_cap=4096,
+                 piv_cap=1 << 16):
+        T = np.ascontiguousarray(final_tableau, dtype=np.float64)
+        x = np.zeros(max(nvars, 1))
+        z = C.c_double()
+        found, best, processed, nrec = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        rp = np.zeros(rec_cap, dtype=np.int32)
+        rk = np.zeros(rec_cap, dtype=np.int32)
+        rd = np.zeros(rec_cap, dtype=np.int32)
+        rv = np.zeros(rec_cap, dtype=np.int32)
+        rb = np.zeros(rec_cap)
+        rs = np.zeros(rec_cap, dtype=np.int32)
+        rz = np.zeros(rec_cap)
+        pop = np.zeros(rec_cap, dtype=np.int32)
+        piv = np.zeros(piv_cap * 4, dtype=np.int32)
+        npiv = C.c_int64()
+        st = self.lib.orc_bb_solve(_dp(T), T.shape[0], T.shape[1], nvars,
+                                   1 if enable_pruning else 0, node_cap, _dp(x), C.byref(z),
+                                   C.byref(found), C.byref(best), C.byref(processed), _ip(rp),
+                                   _ip(rk), _ip(rd), _ip(rv), _dp(rb), _ip(rs), _dp(rz), rec_cap,
+                                   C.byref(nrec), _ip(pop), _ip(piv), piv_cap, C.byref(npiv))
+        k = min(nrec.value, rec_cap)
+        recs = [dict(parent=int(rp[i]), kind=int(rk[i]), depth=int(rd[i]), var=int(rv[i]),
+                     bound=float(rb[i]), status=int(rs[i]), z=float(rz[i])) for i in range(k)]
+        q = min(npiv.value, piv_cap)
+        return dict(status=st, x=x[:nvars] if found.value else None, z=z.value,
+                    found=bool(found.value), best_node=best.value, processed=processed.value,
+                    records=recs, pop_order=pop[:min(processed.value, rec_cap)].tolist(),
+                    trace=[tuple(v) for v in piv[:4 * q].reshape(-1, 4).tolist()])
+
+    def bb_add_constraint(self, base, con):
+        base = np.ascontiguousarray(base, dtype=np.float64)
+        con = np.ascontiguousarray(con, dtype=np.float64)
+        out = np.zeros((base.shape[0] + 1, base.shape[1] + 1))
+        self.lib.orc_bb_add_constraint(_dp(base), base.shape[0], base.shape[1], _dp(con),
+                                       con.shape[0], _dp(out))
+        return out
+
+    def bb_dual_simplex(self, start, piv_cap=1 << 14):
+        start = np.ascontiguousarray(start, dtype=np.float64)
+        out = np.zeros_like(start)
+        npv = C.c_int()
+        piv = np.zeros(piv_cap * 4, dtype=np.int32)
+        n = C.c_int64()
+        rc = self.lib.orc_bb_dual_simplex(_dp(start), start.shape[0], start.shape[1], _dp(out),
+                                          C.byref(npv), _ip(piv), piv_cap, C.byref(n))
+        q = min(n.value, piv_cap)
+        return rc, out, npv.value, [tuple(v[1:]) for v in piv[:4 * q].reshape(-1, 4).tolist()]
+
     # ---- revised ----
     def matmul_skip(self, A, B):
         A = np.ascontiguousarray(A, dtype=np.float64)
