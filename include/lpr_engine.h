@@ -209,6 +209,73 @@ int lpr_revised_xb_read(lpr_revised* s, double* out);
  * (|err| <= 1e-9 * sum_k |b_ik a_kj|), not bit equality -- DESIGN.md. */
 int lpr_revised_binv_a(lpr_revised* s, double* out, double* ms);
 
+/* ------------------------------------------------------- branch and bound */
+
+typedef struct lpr_bb lpr_bb;
+
+/* Replaces BranchAndBoundAdapter.SolveFromPrimal's set-up (IntegerProgramming/
+ * BranchAndBoundAdapter.cs:9-24): Convert(primal.FinalTableau) (:31-46) becomes the root node
+ * (node id 0) in HBM, SetNumVars(nvars) (:20).  max_depth bounds the branching depth (every level
+ * adds one row and one column; node buffers are sized for it; <= 0: 64).
+ *   lpr_bb_create               from a host double[,] (rows x cols row-major)
+ *   lpr_bb_create_from_tableau  from a solved device tableau -- no host round trip */
+int lpr_bb_create(lpr_engine* e, const double* final_tableau, int rows, int cols, int nvars,
+                  int max_depth, lpr_bb** out);
+int lpr_bb_create_from_tableau(lpr_tableau* t, int nvars, int max_depth, lpr_bb** out);
+int lpr_bb_destroy(lpr_bb* b);
+
+typedef struct lpr_bb_opts {
+    int32_t enable_pruning; /* ShouldPrunebranch (:985-1004); Program.cs:389 passes false */
+    int32_t node_cap;       /* <= 0: 20, the reference's hard stop (:1038-1042) */
+    int32_t reserved[2];
+} lpr_bb_opts;
+
+typedef struct lpr_bb_result {
+    int32_t status;        /* LPR_OK_OPTIMAL (stack emptied) or LPR_BB_NODE_CAP */
+    int32_t found;         /* 0: "No integer solution found" -> the C# returns (null, -inf) */
+    int64_t processed;     /* branchCount (:1045) */
+    int32_t best_node;     /* record id of the optimal branch, -1 if none */
+    int32_t reserved;
+    double z;              /* optimalValue (rounded to 4 decimals like every B&B value) */
+    int64_t pivots;        /* dual + primal pivots over all child LPs */
+    int64_t nodes_created; /* node records (root + every child attempted) */
+} lpr_bb_result;
+
+/* Replaces BranchAndBound.ExecuteBranchAndBound (BranchBoundSimplexSolver.cs:1006-1233) in the
+ * reference's own order: DFS stack, lower child first, incumbent replaced on strict improvement,
+ * 4-decimal Math.Round between all stages.  Per popped node the two children (AddConstraint
+ * :694-803, DoDualSimplex :289-468 = PerformDualPivot :115-201 then PerformPrimalPivot :203-279)
+ * are evaluated as one batch on the device.  x (nvars entries) is written when found. */
+int lpr_bb_run(lpr_bb* b, const lpr_bb_opts* opts, double* x, lpr_bb_result* res);
+
+/* Node records of the last lpr_bb_run, in creation order (record 0 = root): parent record, kind
+ * (0 root / 1 lower / 2 upper), depth, branching variable, bound, status (0 solved, 1 infeasible
+ * = DoDualSimplex returned a null optimum, 2 failed = an exception escaped it), rounded z. */
+int lpr_bb_records_read(lpr_bb* b, int32_t* parent, int32_t* kind, int32_t* depth, int32_t* var,
+                        double* bound, int32_t* status, double* z, int64_t cap, int64_t* count);
+/* Record ids in the order the nodes were popped (processed). */
+int lpr_bb_pop_order_read(lpr_bb* b, int32_t* ids, int64_t cap, int64_t* count);
+/* Pivot trace of the last run: quads (record id, phase 0 dual / 1 primal / 2 "last tableau
+ * dropped" :395-400, row, col). */
+int lpr_bb_trace_read(lpr_bb* b, int32_t* quads, int64_t cap, int64_t* count);
+
+/* Building blocks of the same path for callers that drive the tree themselves (the
+ * level-synchronous multi-GPU driver shards the frontier over ranks and calls these per level):
+ *   lpr_bb_node_info  RoundAllTableaux on pop (:1047) + GetObjective (:892-897) + the decision
+ *                     values of CheckIntegerBasicVar / ExtractSolution (:807-827, :899-921);
+ *                     z_out[count], vals_out[count * nvars]
+ *   lpr_bb_expand     for each (parent, var, bound, kind 0 "<=" / 1 ">="): AddConstraint +
+ *                     DoDualSimplex + RoundAllTableaux, all children in one batch;
+ *                     status_out: 2 solved (child_ids_out = new node id), 3 infeasible, 4 failed
+ *   lpr_bb_release    frees node buffers
+ *   lpr_bb_node_read  copies a node tableau to the host (tests / snapshots) */
+int lpr_bb_node_info(lpr_bb* b, const int32_t* ids, int count, double* z_out, double* vals_out);
+int lpr_bb_expand(lpr_bb* b, int count, const int32_t* parent_ids, const int32_t* var,
+                  const double* bound, const int32_t* kind, int32_t* child_ids_out,
+                  int32_t* status_out, int32_t* pivots_out);
+int lpr_bb_release(lpr_bb* b, const int32_t* ids, int count);
+int lpr_bb_node_read(lpr_bb* b, int32_t id, double* out, int32_t* rows, int32_t* cols);
+
 #ifdef __cplusplus
 }
 #endif

@@ -5,6 +5,8 @@ Importing this package loads ``_lib/liblpr_engine.so`` (hand-written HIP for gfx
 """
 from . import _native
 from .engine import Engine, RevisedState, Tableau, default_engine
+from .branch_and_bound import (BranchAndBoundAdapter, BranchBoundTree,
+                               solve_level_synchronous, torch_collectives)
 from .input_file_parser import Constraint, InputFileParser
 from .primal_simplex_solver import PrimalSimplexSolver
 from .revised_primal_simplex_solver import RevisedPrimalSimplexSolver, SolverException
@@ -12,5 +14,6 @@ from .revised_primal_simplex_solver import RevisedPrimalSimplexSolver, SolverExc
 __all__ = [
     "Engine", "Tableau", "default_engine", "Constraint", "InputFileParser",
     "PrimalSimplexSolver", "RevisedPrimalSimplexSolver", "RevisedState", "SolverException",
+    "BranchAndBoundAdapter", "BranchBoundTree", "solve_level_synchronous", "torch_collectives",
     "_native",
 ]

@@ -63,6 +63,27 @@ class RevisedResult(C.Structure):
     ]
 
 
+class BBOpts(C.Structure):
+    _fields_ = [
+        ("enable_pruning", C.c_int32),
+        ("node_cap", C.c_int32),
+        ("reserved", C.c_int32 * 2),
+    ]
+
+
+class BBResult(C.Structure):
+    _fields_ = [
+        ("status", C.c_int32),
+        ("found", C.c_int32),
+        ("processed", C.c_int64),
+        ("best_node", C.c_int32),
+        ("reserved", C.c_int32),
+        ("z", C.c_double),
+        ("pivots", C.c_int64),
+        ("nodes_created", C.c_int64),
+    ]
+
+
 _P = C.c_void_p
 _PP = C.POINTER(C.c_void_p)
 _D = C.POINTER(C.c_double)
@@ -106,6 +127,17 @@ SIGNATURES = {
     "lpr_revised_binv_read": (C.c_int, [_P, _D]),
     "lpr_revised_xb_read": (C.c_int, [_P, _D]),
     "lpr_revised_binv_a": (C.c_int, [_P, _D, _D]),
+    "lpr_bb_create": (C.c_int, [_P, _D, C.c_int, C.c_int, C.c_int, C.c_int, _PP]),
+    "lpr_bb_create_from_tableau": (C.c_int, [_P, C.c_int, C.c_int, _PP]),
+    "lpr_bb_destroy": (C.c_int, [_P]),
+    "lpr_bb_run": (C.c_int, [_P, C.POINTER(BBOpts), _D, C.POINTER(BBResult)]),
+    "lpr_bb_records_read": (C.c_int, [_P, _I32, _I32, _I32, _I32, _D, _I32, _D, C.c_int64, _I64]),
+    "lpr_bb_pop_order_read": (C.c_int, [_P, _I32, C.c_int64, _I64]),
+    "lpr_bb_trace_read": (C.c_int, [_P, _I32, C.c_int64, _I64]),
+    "lpr_bb_node_info": (C.c_int, [_P, _I32, C.c_int, _D, _D]),
+    "lpr_bb_expand": (C.c_int, [_P, C.c_int, _I32, _I32, _D, _I32, _I32, _I32, _I32]),
+    "lpr_bb_release": (C.c_int, [_P, _I32, C.c_int]),
+    "lpr_bb_node_read": (C.c_int, [_P, C.c_int32, _D, _I32, _I32]),
 }
 
 

@@ -1,0 +1,346 @@
+"""Host-side mirror of the Branch & Bound surface of the reference:
+
+* ``BranchAndBoundAdapter.SolveFromPrimal`` (IntegerProgramming/BranchAndBoundAdapter.cs:9-24) --
+  same arguments, same return ``(x, z)``, same InvalidOperationException condition;
+* ``BranchBoundTree`` -- handle wrapper over ``lpr_bb_*`` (include/lpr_engine.h);
+* ``solve_level_synchronous`` -- the multi-GPU driver: the frontier of each level is dealt over the
+  ranks of a ``torch.distributed`` process group (backend "nccl" = RCCL over xGMI on the MI355X
+  node, "gloo" in the CPU tests), every rank expands its share on its own GPU, and ONE
+  ``all_reduce(MAX)`` of the incumbent bound per level keeps the ranks in step.
+
+All tableau arithmetic runs on the device through the C ABI; this module only holds the tree
+bookkeeping the C# keeps in its ``Stack<...>``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _native as N
+from .engine import Engine, Tableau, _dptr, _i32ptr
+
+BB_SOLVED, BB_INFEASIBLE, BB_FAILED = 2, 3, 4  # lpr_bb_expand status codes
+
+
+class BranchBoundTree:
+    """Node pool + batched child evaluation on one GPU (lpr_bb_*)."""
+
+    def __init__(self, engine: Engine, handle: C.c_void_p, nvars: int):
+        self.engine = engine
+        self._h = handle
+        self.nvars = nvars
+
+    @classmethod
+    def from_array(cls, engine: Engine, final_tableau: np.ndarray, nvars: int,
+                   max_depth: int = 0) -> "BranchBoundTree":
+        T = np.ascontiguousarray(final_tableau, dtype=np.float64)
+        h = C.c_void_p()
+        N.check(N.lib.lpr_bb_create(engine._h, _dptr(T), T.shape[0], T.shape[1], nvars, max_depth,
+                                    C.byref(h)), "lpr_bb_create")
+        return cls(engine, h, nvars)
+
+    @classmethod
+    def from_tableau(cls, tab: Tableau, nvars: int, max_depth: int = 0) -> "BranchBoundTree":
+        h = C.c_void_p()
+        N.check(N.lib.lpr_bb_create_from_tableau(tab._h, nvars, max_depth, C.byref(h)),
+                "lpr_bb_create_from_tableau")
+        return cls(tab.engine, h, nvars)
+
+    def destroy(self):
+        if self._h:
+            N.lib.lpr_bb_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+    # ---- the reference's own search order -------------------------------------------------
+    def run(self, enable_pruning: bool = False, node_cap: int = 0):
+        opts = N.BBOpts(enable_pruning=1 if enable_pruning else 0, node_cap=node_cap)
+        res = N.BBResult()
+        x = np.zeros(max(self.nvars, 1), dtype=np.float64)
+        N.check(N.lib.lpr_bb_run(self._h, C.byref(opts), _dptr(x), C.byref(res)), "lpr_bb_run")
+        return res, (x[: self.nvars] if res.found else None)
+
+    def records(self, cap: int = 1 << 16):
+        p = np.zeros(cap, dtype=np.int32)
+        k = np.zeros(cap, dtype=np.int32)
+        d = np.zeros(cap, dtype=np.int32)
+        v = np.zeros(cap, dtype=np.int32)
+        b = np.zeros(cap)
+        s = np.zeros(cap, dtype=np.int32)
+        z = np.zeros(cap)
+        n = C.c_int64()
+        N.check(N.lib.lpr_bb_records_read(self._h, _i32ptr(p), _i32ptr(k), _i32ptr(d), _i32ptr(v),
+                                          _dptr(b), _i32ptr(s), _dptr(z), cap, C.byref(n)),
+                "lpr_bb_records_read")
+        return [dict(parent=int(p[i]), kind=int(k[i]), depth=int(d[i]), var=int(v[i]),
+                     bound=float(b[i]), status=int(s[i]), z=float(z[i])) for i in range(n.value)]
+
+    def pop_order(self, cap: int = 1 << 16) -> List[int]:
+        ids = np.zeros(cap, dtype=np.int32)
+        n = C.c_int64()
+        N.check(N.lib.lpr_bb_pop_order_read(self._h, _i32ptr(ids), cap, C.byref(n)),
+                "lpr_bb_pop_order_read")
+        return ids[: n.value].tolist()
+
+    def trace(self, cap: int = 1 << 20) -> List[Tuple[int, int, int, int]]:
+        q = np.zeros(cap * 4, dtype=np.int32)
+        n = C.c_int64()
+        N.check(N.lib.lpr_bb_trace_read(self._h, _i32ptr(q), cap, C.byref(n)),
+                "lpr_bb_trace_read")
+        return [tuple(v) for v in q[: 4 * n.value].reshape(-1, 4).tolist()]
+
+    # ---- building blocks --------------------------------------------------------------------
+    def node_info(self, ids: Sequence[int]) -> Tuple[np.ndarray, np.ndarray]:
+        ids_a = np.ascontiguousarray(ids, dtype=np.int32)
+        k = ids_a.shape[0]
+        z = np.zeros(max(k, 1))
+        vals = np.zeros((max(k, 1), max(self.nvars, 1)))
+        N.check(N.lib.lpr_bb_node_info(self._h, _i32ptr(ids_a), k, _dptr(z), _dptr(vals)),
+                "lpr_bb_node_info")
+        return z[:k], vals[:k, : self.nvars]
+
+    def expand(self, parents: Sequence[int], var: Sequence[int], bound: Sequence[float],
+               kind: Sequence[int]):
+        p = np.ascontiguousarray(parents, dtype=np.int32)
+        v = np.ascontiguousarray(var, dtype=np.int32)
+        b = np.ascontiguousarray(bound, dtype=np.float64)
+        kd = np.ascontiguousarray(kind, dtype=np.int32)
+        k = p.shape[0]
+        child = np.zeros(max(k, 1), dtype=np.int32)
+        st = np.zeros(max(k, 1), dtype=np.int32)
+        piv = np.zeros(max(k, 1), dtype=np.int32)
+        N.check(N.lib.lpr_bb_expand(self._h, k, _i32ptr(p), _i32ptr(v), _dptr(b), _i32ptr(kd),
+                                    _i32ptr(child), _i32ptr(st), _i32ptr(piv)), "lpr_bb_expand")
+        return child[:k], st[:k], piv[:k]
+
+    def release(self, ids: Sequence[int]) -> None:
+        a = np.ascontiguousarray(ids, dtype=np.int32)
+        if a.shape[0]:
+            N.check(N.lib.lpr_bb_release(self._h, _i32ptr(a), a.shape[0]), "lpr_bb_release")
+
+    def node_read(self, node_id: int) -> np.ndarray:
+        r, c = C.c_int32(), C.c_int32()
+        N.check(N.lib.lpr_bb_node_read(self._h, node_id, None, C.byref(r), C.byref(c)),
+                "lpr_bb_node_read")
+        out = np.empty((r.value, c.value), dtype=np.float64)
+        N.check(N.lib.lpr_bb_node_read(self._h, node_id, _dptr(out), C.byref(r), C.byref(c)),
+                "lpr_bb_node_read")
+        return out
+
+
+class BranchAndBoundAdapter:
+    """IntegerProgramming/BranchAndBoundAdapter.cs:7-51."""
+
+    @staticmethod
+    def SolveFromPrimal(primal, enablePruning: bool = False, isMin: bool = False,
+                        node_cap: int = 0) -> Tuple[List[float], float]:
+        if primal.FinalTableau is None:  # :11-14
+            raise RuntimeError("Primal simplex has not been solved yet.")
+        # :20  SetNumVars(primal.SolutionVector?.Count ?? InferNumVariables(finalTable))
+        nvars = len(primal.SolutionVector) if primal.SolutionVector is not None else \
+            max(1, primal.FinalTableau.shape[1] - 1)
+        # `isMin` is accepted and ignored, as in the reference (never forwarded, :9,:22)
+        tree = BranchBoundTree.from_tableau(primal.tableau, nvars, max_depth=max(node_cap, 20))
+        try:
+            res, x = tree.run(enable_pruning=enablePruning, node_cap=node_cap)
+            tree.last_result = res
+            BranchAndBoundAdapter.last_tree_records = tree.records()
+        finally:
+            tree.destroy()
+        if x is None:
+            return [], -math.inf  # `(x ?? new List<double>(), z)` :23 with optimalValue = -inf
+        return [float(v) for v in x], float(res.z)
+
+
+# ---------------------------------------------------------------------------------------------
+# .NET Framework rounding on the host (tree decisions work on n values per node)
+def _round_int(x: float) -> float:
+    if x != x or x in (math.inf, -math.inf):
+        return x
+    if abs(x) < 9.2e18 and x == float(int(x)):
+        return x
+    t = x + 0.5
+    f = math.floor(t)
+    if f == t and math.fmod(t, 2.0) != 0:
+        f -= 1.0
+    return math.copysign(f, x)
+
+
+def _round4(x: float) -> float:
+    if abs(x) < 1e16:
+        x = x * 10000.0
+        x = _round_int(x)
+        x = x / 10000.0
+    return x
+
+
+def _is_integer(v: float) -> bool:  # BranchBoundSimplexSolver.cs:595-599
+    r = _round4(v)
+    return abs(r - _round_int(r)) <= 1e-6
+
+
+def choose_branch(vals: Sequence[float]) -> Tuple[int, float]:
+    """CheckIntegerBasicVar :829-847: the non-integer value whose fraction is closest to 0.5
+    (strict <, first wins).  Returns (-1, 0.0) when every value is integral."""
+    best, best_val, min_dist = -1, 0.0, math.inf
+    for i, v in enumerate(vals):
+        if not _is_integer(v):
+            d = abs((v - math.floor(v)) - 0.5)
+            if d < min_dist:
+                min_dist, best, best_val = d, i, float(v)
+    return best, best_val
+
+
+def solve_level_synchronous(evaluator, nvars: int, *, rank: int = 0, world: int = 1,
+                            all_reduce_max: Optional[Callable[[float], float]] = None,
+                            gather: Optional[Callable[[object], list]] = None,
+                            enable_pruning: bool = False, max_levels: int = 64,
+                            max_nodes: int = 1 << 20):
+    """Level-synchronous Branch & Bound with the reference's node rules and its cap lifted.
+
+    ``evaluator`` provides ``node_info(ids) -> (z[], vals[][])``, ``expand(parents, var, bound,
+    kind) -> (child_ids, status, pivots)`` and ``release(ids)`` -- a ``BranchBoundTree`` on this
+    rank's GPU (the CPU tests plug a stand-in).  Every rank holds the same root (node 0).
+
+    Sharding without moving a tableau: the first L0 = ceil(log2(world)) levels are evaluated by
+    every rank (identical, deterministic work on tiny frontiers); the depth-L0 frontier, ordered
+    by DFS path, is dealt round-robin and from there on a sub-tree stays on the rank that owns its
+    root -- sub-problems are independent LPs, nothing but the incumbent crosses xGMI.
+
+    Per level: each rank scores its frontier nodes, updates its local incumbent, branches, and
+    evaluates all its children in ONE batched ``expand``; then ONE ``all_reduce(MAX)`` carrying the
+    incumbent objective (and, packed in the same call, whether any rank still has work).  With
+    pruning off (the reference's setting, Program.cs:389) the explored tree does not depend on the
+    rank count, and ties on z go to the node the reference's stack pops first (lower child before
+    upper child, parent before child), so the answer equals ExecuteBranchAndBound without its
+    20-node cap.  Returns dict(x, z, found, processed, pivots, levels, path), same on all ranks."""
+    if all_reduce_max is None:
+        all_reduce_max = lambda v: v  # noqa: E731
+    if gather is None:
+        gather = lambda obj: [obj]  # noqa: E731
+    split_level = 0
+    while (1 << split_level) < world:
+        split_level += 1
+
+    # frontier entries: (node id on this rank, DFS path: tuple of 0 lower / 1 upper)
+    frontier: List[Tuple[int, Tuple[int, ...]]] = [(0, ())]
+    best_local = None  # (z, path, x)
+    best_z = -math.inf
+    global_bound = -math.inf
+    processed = 0
+    pivots = 0
+    levels = 0
+    while levels < max_levels:
+        replicated = levels < split_level  # every rank is doing the same nodes
+        count_here = (not replicated) or rank == 0
+        parents, var, bound, kind, paths = [], [], [], [], []
+        if frontier:
+            ids = [nid for nid, _ in frontier]
+            zs, vals = evaluator.node_info(ids)
+            for (nid, path), z, v in zip(frontier, zs, vals):
+                if count_here:
+                    processed += 1
+                if enable_pruning and global_bound > -math.inf and z <= global_bound:
+                    continue  # ShouldPrunebranch :995-1001 against the all-reduced bound
+                if all(_is_integer(t) for t in v):  # UpdateOptimalSolution :943-981
+                    cand = (float(z), path, [float(t) for t in v])
+                    if best_local is None or cand[0] > best_local[0] or \
+                            (cand[0] == best_local[0] and _dfs_before(cand[1], best_local[1])):
+                        best_local = cand
+                        best_z = max(best_z, cand[0])
+                k, val = choose_branch(v)  # CreateBranches :859-890
+                if k < 0:
+                    continue
+                for side, bnd in ((0, math.floor(val)), (1, math.ceil(val))):
+                    parents.append(nid)
+                    var.append(k)
+                    bound.append(float(int(bnd)))
+                    kind.append(side)
+                    paths.append(path + (side,))
+        new_frontier: List[Tuple[int, Tuple[int, ...]]] = []
+        if parents:
+            child, st, piv = evaluator.expand(parents, var, bound, kind)
+            if count_here:
+                pivots += int(np.sum(piv))
+            for c, s2, pth in zip(child, st, paths):
+                if s2 == BB_SOLVED:
+                    new_frontier.append((int(c), pth))
+        if frontier:
+            evaluator.release([nid for nid, _ in frontier])
+        levels += 1
+        if levels == split_level and world > 1:
+            # deal the depth-L0 frontier: identical on every rank, so no communication is needed
+            new_frontier.sort(key=lambda e: e[1])
+            keep = [e for i, e in enumerate(new_frontier) if i % world == rank]
+            drop = [e[0] for i, e in enumerate(new_frontier) if i % world != rank]
+            if drop:
+                evaluator.release(drop)
+            new_frontier = keep
+        frontier = new_frontier
+        # ---- the single collective of the level (RCCL all-reduce over xGMI): the incumbent
+        # bound; "someone still has nodes" rides in the same MAX as a large offset-free flag ----
+        global_bound, busy = _reduce_bound_and_busy(all_reduce_max, best_z, bool(frontier))
+        if not busy or processed > max_nodes:
+            break
+    if frontier:
+        evaluator.release([nid for nid, _ in frontier])
+    # winner identity: one gather at termination, ties by DFS order (:966 "first found wins")
+    cands = [c for c in gather(best_local) if c is not None]
+    total_processed = int(sum(gather(processed)))
+    total_pivots = int(sum(gather(pivots)))
+    if not cands:
+        return dict(x=None, z=-math.inf, found=False, processed=total_processed,
+                    pivots=total_pivots, levels=levels, path=None)
+    best = cands[0]
+    for c in cands[1:]:
+        if c[0] > best[0] or (c[0] == best[0] and _dfs_before(c[1], best[1])):
+            best = c
+    return dict(x=best[2], z=best[0], found=True, processed=total_processed,
+                pivots=total_pivots, levels=levels, path=best[1])
+
+
+def _reduce_bound_and_busy(all_reduce_max, best_z: float, busy: bool):
+    """One MAX all-reduce of a 2-vector (bound, busy flag).  ``all_reduce_max`` may take a float
+    (tests) or a 2-list; both are supported so that the production path issues ONE collective."""
+    try:
+        out = all_reduce_max([best_z, 1.0 if busy else 0.0])
+        return float(out[0]), bool(out[1] > 0.5)
+    except TypeError:
+        return float(all_reduce_max(best_z)), bool(all_reduce_max(1.0 if busy else 0.0) > 0.5)
+
+
+def _dfs_before(a: Tuple[int, ...], b: Tuple[int, ...]) -> bool:
+    """True if node `a` is popped before node `b` by the reference's stack (pre-order, lower
+    child first): lexicographic order on the branch paths, a prefix (ancestor) first."""
+    return a < b
+
+
+def torch_collectives(group=None):
+    """(all_reduce_max, gather) over a torch.distributed process group -- backend "nccl" is RCCL
+    on the MI355X node (xGMI), "gloo" on CPU.  The all-reduce moves one 16-byte tensor."""
+    import torch
+    import torch.distributed as dist
+
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+
+    def all_reduce_max(v):
+        t = torch.tensor(v if isinstance(v, (list, tuple)) else [v], dtype=torch.float64,
+                         device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        out = t.cpu().tolist()
+        return out if isinstance(v, (list, tuple)) else out[0]
+
+    def gather(obj):
+        out = [None] * dist.get_world_size(group)
+        dist.all_gather_object(out, obj, group=group)
+        return out
+
+    return all_reduce_max, gather

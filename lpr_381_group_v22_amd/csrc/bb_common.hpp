@@ -1,0 +1,83 @@
+// bb_common.hpp -- internal state of the Branch & Bound engine (IntegerProgramming/
+// BranchBoundSimplexSolver.cs on the device).  Not part of the ABI.
+#pragma once
+
+#include "engine_common.hpp"
+
+namespace lpr {
+
+// States of one child LP while DoDualSimplex (:289-468) runs on it.
+enum : int32_t {
+    kBBDual = 0,        // dual phase (:305-343)
+    kBBPrimal = 1,      // primal phase (:352-390)
+    kBBSolved = 2,      // optimalValue != null
+    kBBInfeasible = 3,  // PerformDualPivot gave up -> optimalValue == null (:324-331)
+    kBBFailed = 4       // an exception escaped DoDualSimplex (RemoveAt on an empty list, :396-399)
+};
+
+// One child sub-problem being evaluated (device memory, one per slot of the current batch).
+struct BBSlot {
+    double* cur;       // current tableau ("tableaux.Last()"), rows x ld
+    double* nxt;       // the other buffer of the ping-pong pair: the previous tableau
+    int32_t rows, cols;
+    int32_t state;
+    int32_t pivots;    // tableaux.Count - 1
+    int32_t pr, pc;    // pivot chosen by k_bb_select for the pending update
+    int32_t do_update; // 1: k_bb_update must run for this slot, then cur/nxt are swapped
+    int32_t reverse;   // constraint type of the branching row (1: ">=", AddConstraint :774-775)
+    int32_t var;       // branching variable
+    int32_t crow;      // index of the appended constraint row
+    int32_t trace_n;   // entries written to this slot's pivot trace
+    int32_t pad;
+    double bound;
+    const double* parent;  // parent node's (rounded) tableau, (rows-1) x (cols-1)
+};
+
+}  // namespace lpr
+
+struct lpr_bb {
+    lpr_engine* eng = nullptr;
+    int rows0 = 0, cols0 = 0;   // root tableau shape
+    int nvars = 0;
+    int max_depth = 0;
+    int rows_cap = 0, ld = 0;   // every node buffer is rows_cap x ld doubles
+    size_t buf_elems = 0;
+    // node pool
+    struct Node {
+        double* T = nullptr;
+        int rows = 0, cols = 0, depth = 0;
+        bool live = false;
+    };
+    std::vector<Node> nodes;          // node id -> buffer
+    std::vector<double*> free_bufs;   // recycled device buffers
+    std::vector<double*> all_bufs;    // everything ever allocated (freed at destroy)
+    // batch scratch (grown on demand)
+    int slot_cap = 0;
+    lpr::BBSlot* d_slots = nullptr;
+    lpr::BBSlot* h_slots = nullptr;   // pinned
+    double* rowbuf = nullptr;         // slot_cap x ld
+    double* colbuf = nullptr;         // slot_cap x rows_cap
+    int32_t* bflag = nullptr;         // slot_cap x ld   IdentifyBasicVariables: column is "basic"
+    int32_t* bkey = nullptr;          // slot_cap x ld   row of its first 1.0 (or rows)
+    int32_t* blist = nullptr;         // slot_cap x ld   sorted basic columns
+    int32_t* bcount = nullptr;        // slot_cap
+    int32_t* trace = nullptr;         // slot_cap x trace_cap x 3 (phase, row, col)
+    int trace_cap = 0;
+    double* info = nullptr;           // slot_cap x (nvars + 1): z, decision values
+    double* h_info = nullptr;         // pinned
+    int32_t* d_running = nullptr;     // number of slots still in kBBDual / kBBPrimal
+    int32_t* h_running = nullptr;     // pinned
+    // host-side results of lpr_bb_run
+    struct Rec {
+        int32_t parent, kind, depth, var, status;
+        double bound, z;
+    };
+    std::vector<Rec> records;
+    std::vector<int32_t> pop_order;
+    std::vector<int32_t> piv_trace;   // quads (record id, phase, row, col)
+    std::vector<double> best_x;
+    double best_z = 0.0;
+    int best_node = -1;
+    bool found = false;
+    int64_t total_pivots = 0;
+};

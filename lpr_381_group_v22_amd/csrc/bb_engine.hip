@@ -1,0 +1,630 @@
+// bb_engine.hip -- C ABI of the Branch & Bound path (include/lpr_engine.h, lpr_bb_*).
+//
+// The tree logic of BranchAndBound.ExecuteBranchAndBound (IntegerProgramming/
+// BranchBoundSimplexSolver.cs:1006-1233) -- a stack, a few comparisons per node -- runs on the
+// host; every tableau operation (RoundTableau, IdentifyBasicVariables, AddConstraint, the dual /
+// primal pivots of DoDualSimplex, the decision-value scans) runs on the device, batched over the
+// children that are evaluated together.  Node tableaux never leave HBM.  No CPU fallback.
+#include "bb_common.hpp"
+
+#include <cmath>
+#include <new>
+
+#pragma clang fp contract(off)
+
+namespace lpr {
+
+// bb_kernels.hip
+void bb_launch_copy_in(lpr_bb* b, const double* src, int src_ld, int rows, int cols, double* dst);
+void bb_launch_round(lpr_bb* b, int nslots, int rows_max, int clean);
+void bb_launch_node_info(lpr_bb* b, int count);
+void bb_launch_add_constraint(lpr_bb* b, int nslots, int rows_max, int cols_max);
+void bb_launch_pivot_step(lpr_bb* b, int nslots, int rows_max, int cols_max);
+void bb_launch_select_only(lpr_bb* b, int nslots, int rows_max, int cols_max);
+
+// ---- .NET Framework rounding on the host (IsInteger :595-599 works on n values per node) ----
+static double dn_round_int(double x) {  // Math.Round(double), COMDouble::Round
+    if (std::isnan(x) || std::isinf(x)) return x;
+    if (std::fabs(x) < 9.2e18 && x == (double)((long long)x)) return x;
+    const double t = x + 0.5;
+    double f = std::floor(t);
+    if (f == t && std::fmod(t, 2.0) != 0) f -= 1.0;
+    return std::copysign(f, x);
+}
+static double dn_round4(double x) {  // Math.Round(double, 4)
+    if (std::fabs(x) < 1e16) {
+        x = x * 10000.0;
+        x = dn_round_int(x);
+        x = x / 10000.0;
+    }
+    return x;
+}
+static bool is_integer(double v) {  // :595-599
+    const double r = dn_round4(v);
+    return std::fabs(r - dn_round_int(r)) <= 1e-6;
+}
+
+static void bb_release_device(lpr_bb* b) {
+    hipSetDevice(b->eng->device);
+    if (b->eng->stream) hipStreamSynchronize(b->eng->stream);
+    for (double* p : b->all_bufs) hipFree(p);
+    b->all_bufs.clear();
+    b->free_bufs.clear();
+    b->nodes.clear();
+    hipFree(b->d_slots); hipFree(b->rowbuf); hipFree(b->colbuf); hipFree(b->bflag);
+    hipFree(b->bkey); hipFree(b->blist); hipFree(b->bcount); hipFree(b->trace); hipFree(b->info);
+    hipFree(b->d_running);
+    if (b->h_slots) hipHostFree(b->h_slots);
+    if (b->h_info) hipHostFree(b->h_info);
+    if (b->h_running) hipHostFree(b->h_running);
+    b->d_slots = b->h_slots = nullptr;
+    b->rowbuf = b->colbuf = b->info = b->h_info = nullptr;
+    b->bflag = b->bkey = b->blist = b->bcount = b->trace = b->d_running = b->h_running = nullptr;
+    b->slot_cap = 0;
+}
+
+void bb_orphan(lpr_bb* b) {
+    bb_release_device(b);
+    b->eng = nullptr;
+}
+
+static int bb_alloc_buf(lpr_bb* b, double** out) {
+    if (!b->free_bufs.empty()) {
+        *out = b->free_bufs.back();
+        b->free_bufs.pop_back();
+        return LPR_OK_OPTIMAL;
+    }
+    double* p = nullptr;
+    hipError_t err = hipMalloc(&p, b->buf_elems * sizeof(double));
+    if (err != hipSuccess) {
+        set_error("B&B node buffer allocation (%zu bytes) failed: %s",
+                  b->buf_elems * sizeof(double), hipGetErrorString(err));
+        return err == hipErrorOutOfMemory ? LPR_OUT_OF_MEMORY : LPR_DEVICE_ERROR;
+    }
+    b->all_bufs.push_back(p);
+    *out = p;
+    return LPR_OK_OPTIMAL;
+}
+
+static int bb_ensure_slots(lpr_bb* b, int need) {
+    if (need <= b->slot_cap) return LPR_OK_OPTIMAL;
+    int cap = b->slot_cap ? b->slot_cap : 2;
+    while (cap < need) cap *= 2;
+    LPR_HIP(hipStreamSynchronize(b->eng->stream));
+    hipFree(b->d_slots); hipFree(b->rowbuf); hipFree(b->colbuf); hipFree(b->bflag);
+    hipFree(b->bkey); hipFree(b->blist); hipFree(b->bcount); hipFree(b->trace); hipFree(b->info);
+    if (b->h_slots) hipHostFree(b->h_slots);
+    if (b->h_info) hipHostFree(b->h_info);
+    b->d_slots = b->h_slots = nullptr;
+    b->rowbuf = b->colbuf = b->info = b->h_info = nullptr;
+    b->bflag = b->bkey = b->blist = b->bcount = b->trace = nullptr;
+    b->slot_cap = 0;
+    b->trace_cap = 4 * (b->rows_cap + b->ld) + 64;  // generous: pivots per child LP
+    const size_t S = (size_t)cap;
+    LPR_HIP(hipMalloc(&b->d_slots, S * sizeof(BBSlot)));
+    LPR_HIP(hipHostMalloc(&b->h_slots, S * sizeof(BBSlot)));
+    LPR_HIP(hipMalloc(&b->rowbuf, S * b->ld * sizeof(double)));
+    LPR_HIP(hipMalloc(&b->colbuf, S * b->rows_cap * sizeof(double)));
+    LPR_HIP(hipMalloc(&b->bflag, S * b->ld * sizeof(int32_t)));
+    LPR_HIP(hipMalloc(&b->bkey, S * b->ld * sizeof(int32_t)));
+    LPR_HIP(hipMalloc(&b->blist, S * b->ld * sizeof(int32_t)));
+    LPR_HIP(hipMalloc(&b->bcount, S * sizeof(int32_t)));
+    LPR_HIP(hipMalloc(&b->trace, S * b->trace_cap * 3 * sizeof(int32_t)));
+    LPR_HIP(hipMalloc(&b->info, S * (b->nvars + 1) * sizeof(double)));
+    LPR_HIP(hipHostMalloc(&b->h_info, S * (b->nvars + 1) * sizeof(double)));
+    if (!b->d_running) {
+        LPR_HIP(hipMalloc(&b->d_running, sizeof(int32_t)));
+        LPR_HIP(hipHostMalloc(&b->h_running, sizeof(int32_t)));
+    }
+    b->slot_cap = cap;
+    return LPR_OK_OPTIMAL;
+}
+
+static int bb_new_node(lpr_bb* b, double* T, int rows, int cols, int depth) {
+    lpr_bb::Node nd;
+    nd.T = T;
+    nd.rows = rows;
+    nd.cols = cols;
+    nd.depth = depth;
+    nd.live = true;
+    b->nodes.push_back(nd);
+    return (int)b->nodes.size() - 1;
+}
+
+// RoundAllTableaux on pop (:1047) + GetObjective / decision values for `count` nodes.
+// z_out[count], vals_out[count * nvars].
+static int bb_node_info(lpr_bb* b, const int32_t* ids, int count, double* z_out,
+                        double* vals_out) {
+    if (count <= 0) return LPR_OK_OPTIMAL;
+    int rc = bb_ensure_slots(b, count);
+    if (rc != LPR_OK_OPTIMAL) return rc;
+    hipStream_t st = b->eng->stream;
+    int rows_max = 0;
+    for (int k = 0; k < count; ++k) {
+        const int id = ids[k];
+        if (id < 0 || id >= (int)b->nodes.size() || !b->nodes[id].live) {
+            set_error("lpr_bb: node %d is not live", id);
+            return LPR_BAD_ARGUMENT;
+        }
+        BBSlot& s = b->h_slots[k];
+        std::memset(&s, 0, sizeof s);
+        s.cur = b->nodes[id].T;
+        s.rows = b->nodes[id].rows;
+        s.cols = b->nodes[id].cols;
+        rows_max = s.rows > rows_max ? s.rows : rows_max;
+    }
+    LPR_HIP(hipMemcpyAsync(b->d_slots, b->h_slots, (size_t)count * sizeof(BBSlot),
+                           hipMemcpyHostToDevice, st));
+    bb_launch_round(b, count, rows_max, 0);  // currentTableaux = RoundAllTableaux(...) :1047
+    bb_launch_node_info(b, count);
+    LPR_HIP(hipGetLastError());
+    LPR_HIP(hipMemcpyAsync(b->h_info, b->info, (size_t)count * (b->nvars + 1) * sizeof(double),
+                           hipMemcpyDeviceToHost, st));
+    LPR_HIP(hipStreamSynchronize(st));
+    for (int k = 0; k < count; ++k) {
+        const double* p = b->h_info + (size_t)k * (b->nvars + 1);
+        z_out[k] = p[0];
+        for (int i = 0; i < b->nvars; ++i) vals_out[(size_t)k * b->nvars + i] = p[1 + i];
+    }
+    return LPR_OK_OPTIMAL;
+}
+
+// AddConstraint (:694-803) + DoDualSimplex (:289-468) + RoundAllTableaux (:1124/:1187) for `count`
+// children, all in one batch.  kind: 0 = lower ("<=", type 0), 1 = upper (">=", type 1).
+// status_out: kBBSolved / kBBInfeasible / kBBFailed; child_ids_out: node id or -1.
+static int bb_expand(lpr_bb* b, int count, const int32_t* parent_ids, const int32_t* var,
+                     const double* bound, const int32_t* kind, int32_t* child_ids_out,
+                     int32_t* status_out, int32_t* pivots_out,
+                     std::vector<int32_t>* trace_out /* triples per child, flattened */,
+                     std::vector<int32_t>* trace_off) {
+    if (count <= 0) return LPR_OK_OPTIMAL;
+    int rc = bb_ensure_slots(b, count);
+    if (rc != LPR_OK_OPTIMAL) return rc;
+    hipStream_t st = b->eng->stream;
+    int rows_max = 0, cols_max = 0;
+    for (int k = 0; k < count; ++k) {
+        const int pid = parent_ids[k];
+        if (pid < 0 || pid >= (int)b->nodes.size() || !b->nodes[pid].live) {
+            set_error("lpr_bb: parent node %d is not live", pid);
+            return LPR_BAD_ARGUMENT;
+        }
+        const lpr_bb::Node& pn = b->nodes[pid];
+        if (pn.rows + 1 > b->rows_cap || align_up(pn.cols + 1, kLdAlign) > b->ld) {
+            set_error("lpr_bb: depth limit reached (max_depth=%d)", b->max_depth);
+            return LPR_BB_NODE_CAP;
+        }
+        BBSlot& s = b->h_slots[k];
+        std::memset(&s, 0, sizeof s);
+        rc = bb_alloc_buf(b, &s.cur);
+        if (rc != LPR_OK_OPTIMAL) return rc;
+        rc = bb_alloc_buf(b, &s.nxt);
+        if (rc != LPR_OK_OPTIMAL) return rc;
+        s.rows = pn.rows + 1;
+        s.cols = pn.cols + 1;
+        s.state = kBBDual;
+        s.reverse = kind[k] ? 1 : 0;
+        s.var = var[k];
+        s.crow = pn.rows;
+        s.bound = bound[k];
+        s.parent = pn.T;
+        rows_max = s.rows > rows_max ? s.rows : rows_max;
+        cols_max = s.cols > cols_max ? s.cols : cols_max;
+    }
+    LPR_HIP(hipMemcpyAsync(b->d_slots, b->h_slots, (size_t)count * sizeof(BBSlot),
+                           hipMemcpyHostToDevice, st));
+    *b->h_running = count;
+    LPR_HIP(hipMemcpyAsync(b->d_running, b->h_running, sizeof(int32_t), hipMemcpyHostToDevice,
+                           st));
+    bb_launch_add_constraint(b, count, rows_max, cols_max);
+
+    // DoDualSimplex: pivot steps until every child has left the running states
+    const int poll = 4;
+    int64_t guard = 0;
+    for (;;) {
+        // k_bb_select and k_bb_update always run as a pair: a select that starts a pivot sets
+        // do_update, and the NEXT select swaps cur/nxt on the strength of that flag
+        for (int k = 0; k < poll; ++k) bb_launch_pivot_step(b, count, rows_max, cols_max);
+        LPR_HIP(hipGetLastError());
+        LPR_HIP(hipMemcpyAsync(b->h_running, b->d_running, sizeof(int32_t), hipMemcpyDeviceToHost,
+                               st));
+        LPR_HIP(hipStreamSynchronize(st));
+        if (*b->h_running <= 0) break;
+        if (++guard > (1 << 16)) {
+            // the reference has no pivot cap either (a cycling LP spins for ever in the C#);
+            // the engine gives up instead of hanging the stream
+            set_error("lpr_bb: DoDualSimplex did not terminate (cycling LP?)");
+            return LPR_PIVOT_LIMIT;
+        }
+    }
+    // the loop only ends when no slot is running; the select that finishes a slot leaves
+    // do_update = 0, so every cur/nxt swap is settled here
+    bb_launch_round(b, count, rows_max, 0);  // RoundAllTableaux(newTableaux) :1124 / :1187
+    LPR_HIP(hipGetLastError());
+    LPR_HIP(hipMemcpyAsync(b->h_slots, b->d_slots, (size_t)count * sizeof(BBSlot),
+                           hipMemcpyDeviceToHost, st));
+    std::vector<int32_t> tr;
+    if (trace_out) {
+        tr.resize((size_t)count * b->trace_cap * 3);
+        LPR_HIP(hipMemcpyAsync(tr.data(), b->trace, tr.size() * sizeof(int32_t),
+                               hipMemcpyDeviceToHost, st));
+    }
+    LPR_HIP(hipStreamSynchronize(st));
+    for (int k = 0; k < count; ++k) {
+        const BBSlot& s = b->h_slots[k];
+        status_out[k] = s.state;
+        if (pivots_out) pivots_out[k] = s.pivots;
+        b->total_pivots += s.trace_n;
+        if (trace_out) {
+            trace_off->push_back((int32_t)trace_out->size());
+            const int nt = s.trace_n < b->trace_cap ? s.trace_n : b->trace_cap;
+            const int32_t* src = tr.data() + (size_t)k * b->trace_cap * 3;
+            trace_out->insert(trace_out->end(), src, src + (size_t)nt * 3);
+        }
+        if (s.state == kBBSolved) {
+            child_ids_out[k] = bb_new_node(b, s.cur, s.rows, s.cols,
+                                           b->nodes[parent_ids[k]].depth + 1);
+            b->free_bufs.push_back(s.nxt);
+        } else {
+            child_ids_out[k] = -1;
+            b->free_bufs.push_back(s.cur);
+            b->free_bufs.push_back(s.nxt);
+        }
+    }
+    if (trace_out) trace_off->push_back((int32_t)trace_out->size());
+    return LPR_OK_OPTIMAL;
+}
+
+static void bb_release_node(lpr_bb* b, int id) {
+    if (id < 0 || id >= (int)b->nodes.size() || !b->nodes[id].live) return;
+    b->nodes[id].live = false;
+    b->free_bufs.push_back(b->nodes[id].T);
+    b->nodes[id].T = nullptr;
+}
+
+static int bb_create_common(lpr_engine* e, int rows, int cols, int nvars, int max_depth,
+                            lpr_bb** out) {
+    if (!e || !out || rows < 1 || cols < 2 || nvars < 0 || nvars > cols - 1) {
+        set_error("lpr_bb_create: bad arguments (rows=%d cols=%d nvars=%d)", rows, cols, nvars);
+        return LPR_BAD_ARGUMENT;
+    }
+    if (max_depth <= 0) max_depth = 64;
+    if (rows + max_depth > 65535) {
+        set_error("lpr_bb_create: rows + max_depth exceeds 65535");
+        return LPR_BAD_ARGUMENT;
+    }
+    LPR_HIP(hipSetDevice(e->device));
+    lpr_bb* b = new (std::nothrow) lpr_bb();
+    if (!b) return LPR_OUT_OF_MEMORY;
+    b->eng = e;
+    b->rows0 = rows;
+    b->cols0 = cols;
+    b->nvars = nvars;
+    b->max_depth = max_depth;
+    b->rows_cap = rows + max_depth;
+    b->ld = align_up(cols + max_depth, kLdAlign);
+    b->buf_elems = (size_t)b->rows_cap * b->ld;
+    e->live_bb.push_back(b);
+    *out = b;
+    return LPR_OK_OPTIMAL;
+}
+
+}  // namespace lpr
+
+using namespace lpr;
+
+#define LPR_LIVE_BB(b)                                                              \
+    do {                                                                            \
+        if (!(b) || !(b)->eng) {                                                    \
+            set_error("B&B handle is null or its engine has been closed");         \
+            return LPR_BAD_ARGUMENT;                                                \
+        }                                                                           \
+    } while (0)
+
+extern "C" {
+
+int lpr_bb_create(lpr_engine* e, const double* final_tableau, int rows, int cols, int nvars,
+                  int max_depth, lpr_bb** out) {
+    if (!final_tableau) {
+        set_error("lpr_bb_create: null tableau");
+        return LPR_BAD_ARGUMENT;
+    }
+    lpr_bb* b = nullptr;
+    int rc = bb_create_common(e, rows, cols, nvars, max_depth, &b);
+    if (rc != LPR_OK_OPTIMAL) return rc;
+    double* T = nullptr;
+    rc = bb_alloc_buf(b, &T);
+    if (rc != LPR_OK_OPTIMAL) {
+        lpr_bb_destroy(b);
+        return rc;
+    }
+    hipStream_t st = e->stream;
+    hipError_t err = hipMemsetAsync(T, 0, b->buf_elems * sizeof(double), st);
+    if (err == hipSuccess)
+        err = hipMemcpy2DAsync(T, (size_t)b->ld * sizeof(double), final_tableau,
+                               (size_t)cols * sizeof(double), (size_t)cols * sizeof(double), rows,
+                               hipMemcpyHostToDevice, st);
+    if (err == hipSuccess) err = hipStreamSynchronize(st);
+    if (err != hipSuccess) {
+        set_error("lpr_bb_create: %s", hipGetErrorString(err));
+        lpr_bb_destroy(b);
+        return LPR_DEVICE_ERROR;
+    }
+    bb_new_node(b, T, rows, cols, 0);  // node 0 = the root (Convert(primal.FinalTableau))
+    *out = b;
+    return LPR_OK_OPTIMAL;
+}
+
+int lpr_bb_create_from_tableau(lpr_tableau* t, int nvars, int max_depth, lpr_bb** out) {
+    if (!t || !t->eng) {
+        set_error("lpr_bb_create_from_tableau: tableau handle is null or orphaned");
+        return LPR_BAD_ARGUMENT;
+    }
+    lpr_bb* b = nullptr;
+    int rc = bb_create_common(t->eng, t->rows, t->cols, nvars, max_depth, &b);
+    if (rc != LPR_OK_OPTIMAL) return rc;
+    double* T = nullptr;
+    rc = bb_alloc_buf(b, &T);
+    if (rc != LPR_OK_OPTIMAL) {
+        lpr_bb_destroy(b);
+        return rc;
+    }
+    bb_launch_copy_in(b, t->T, t->ld, t->rows, t->cols, T);  // device -> device, no host trip
+    hipError_t err = hipGetLastError();
+    if (err == hipSuccess) err = hipStreamSynchronize(t->eng->stream);
+    if (err != hipSuccess) {
+        set_error("lpr_bb_create_from_tableau: %s", hipGetErrorString(err));
+        lpr_bb_destroy(b);
+        return LPR_DEVICE_ERROR;
+    }
+    bb_new_node(b, T, t->rows, t->cols, 0);
+    *out = b;
+    return LPR_OK_OPTIMAL;
+}
+
+int lpr_bb_destroy(lpr_bb* b) {
+    if (!b) return LPR_BAD_ARGUMENT;
+    if (b->eng) {
+        bb_release_device(b);
+        auto& lv = b->eng->live_bb;
+        for (size_t k = 0; k < lv.size(); ++k)
+            if (lv[k] == b) {
+                lv.erase(lv.begin() + k);
+                break;
+            }
+    }
+    delete b;
+    return LPR_OK_OPTIMAL;
+}
+
+int lpr_bb_node_info(lpr_bb* b, const int32_t* ids, int count, double* z_out, double* vals_out) {
+    LPR_LIVE_BB(b);
+    if (count < 0 || (count > 0 && (!ids || !z_out || (b->nvars > 0 && !vals_out))))
+        return LPR_BAD_ARGUMENT;
+    LPR_HIP(hipSetDevice(b->eng->device));
+    return bb_node_info(b, ids, count, z_out, vals_out);
+}
+
+int lpr_bb_expand(lpr_bb* b, int count, const int32_t* parent_ids, const int32_t* var,
+                  const double* bound, const int32_t* kind, int32_t* child_ids_out,
+                  int32_t* status_out, int32_t* pivots_out) {
+    LPR_LIVE_BB(b);
+    if (count < 0 || (count > 0 && (!parent_ids || !var || !bound || !kind || !child_ids_out ||
+                                    !status_out)))
+        return LPR_BAD_ARGUMENT;
+    for (int k = 0; k < count; ++k)
+        if (var[k] < 0 || var[k] >= b->nvars) {
+            set_error("lpr_bb_expand: branching variable %d out of range", var[k]);
+            return LPR_BAD_ARGUMENT;
+        }
+    LPR_HIP(hipSetDevice(b->eng->device));
+    return bb_expand(b, count, parent_ids, var, bound, kind, child_ids_out, status_out,
+                     pivots_out, nullptr, nullptr);
+}
+
+int lpr_bb_release(lpr_bb* b, const int32_t* ids, int count) {
+    LPR_LIVE_BB(b);
+    for (int k = 0; k < count; ++k) bb_release_node(b, ids[k]);
+    return LPR_OK_OPTIMAL;
+}
+
+int lpr_bb_node_read(lpr_bb* b, int32_t id, double* out, int32_t* rows, int32_t* cols) {
+    LPR_LIVE_BB(b);
+    if (id < 0 || id >= (int)b->nodes.size() || !b->nodes[id].live) {
+        set_error("lpr_bb_node_read: node %d is not live", id);
+        return LPR_BAD_ARGUMENT;
+    }
+    const lpr_bb::Node& nd = b->nodes[id];
+    if (rows) *rows = nd.rows;
+    if (cols) *cols = nd.cols;
+    if (!out) return LPR_OK_OPTIMAL;
+    LPR_HIP(hipSetDevice(b->eng->device));
+    hipStream_t st = b->eng->stream;
+    LPR_HIP(hipMemcpy2DAsync(out, (size_t)nd.cols * sizeof(double), nd.T,
+                             (size_t)b->ld * sizeof(double), (size_t)nd.cols * sizeof(double),
+                             nd.rows, hipMemcpyDeviceToHost, st));
+    LPR_HIP(hipStreamSynchronize(st));
+    return LPR_OK_OPTIMAL;
+}
+
+// ExecuteBranchAndBound (:1006-1233): DFS stack, lower child first, incumbent replaced on strict
+// improvement only, optional pruning, node cap (20 in the reference).
+int lpr_bb_run(lpr_bb* b, const lpr_bb_opts* opts, double* x, lpr_bb_result* res) {
+    LPR_LIVE_BB(b);
+    if (!res) return LPR_BAD_ARGUMENT;
+    LPR_HIP(hipSetDevice(b->eng->device));
+    lpr_bb_opts o;
+    std::memset(&o, 0, sizeof o);
+    if (opts) o = *opts;
+    const int node_cap = o.node_cap > 0 ? o.node_cap : 20;  // :1038
+    const int n = b->nvars;
+    if (b->nodes.empty() || !b->nodes[0].live) {
+        set_error("lpr_bb_run: the root node has been consumed; create a new handle");
+        return LPR_BAD_ARGUMENT;
+    }
+
+    b->records.clear();
+    b->pop_order.clear();
+    b->piv_trace.clear();
+    b->best_x.assign(n > 0 ? n : 1, 0.0);
+    b->best_z = -INFINITY;  // :1024 (isMinimization is never set by the adapter)
+    b->best_node = -1;
+    b->found = false;
+    b->total_pivots = 0;
+
+    // initialTableaux = RoundAllTableaux(initialTableaux) :1021 -- the pop rounds again (:1047)
+    std::vector<double> vals((size_t)(n > 0 ? n : 1));
+    struct Item { int node; int depth; int rec; };
+    std::vector<Item> stack;
+    {
+        int32_t root = 0;
+        double z0 = 0;
+        int rc = bb_node_info(b, &root, 1, &z0, vals.data());
+        if (rc != LPR_OK_OPTIMAL) return rc;
+        b->records.push_back({-1, 0, 0, -1, 0, 0.0, z0});
+        stack.push_back({0, 0, 0});
+    }
+
+    int status = LPR_OK_OPTIMAL;
+    int iteration = 0;
+    int64_t processed = 0;
+    while (!stack.empty()) {
+        ++iteration;
+        if (iteration > node_cap) {  // "Potential infinite loop detected" :1038-1042
+            status = LPR_BB_NODE_CAP;
+            break;
+        }
+        const Item it = stack.back();
+        stack.pop_back();
+        b->pop_order.push_back(it.rec);
+        ++processed;
+        int32_t nid = it.node;
+        double objVal = 0;
+        int rc = bb_node_info(b, &nid, 1, &objVal, vals.data());  // :1047, :892-897, :899-921
+        if (rc != LPR_OK_OPTIMAL) return rc;
+
+        if (o.enable_pruning && b->found && objVal <= b->best_z) {  // ShouldPrunebranch :985-1004
+            bb_release_node(b, nid);
+            continue;
+        }
+        bool allInt = true;  // UpdateOptimalSolution :935-983
+        for (int i = 0; i < n; ++i)
+            if (!is_integer(vals[i])) { allInt = false; break; }
+        if (allInt && objVal > b->best_z) {
+            b->best_z = objVal;
+            for (int i = 0; i < n; ++i) b->best_x[i] = vals[i];
+            b->found = true;
+            b->best_node = it.rec;
+        }
+        int bestVar = -1;  // CheckIntegerBasicVar :829-847
+        double bestValue = 0, minDist = INFINITY;
+        for (int i = 0; i < n; ++i) {
+            if (!is_integer(vals[i])) {
+                const double frac = vals[i] - std::floor(vals[i]);
+                const double dist = std::fabs(frac - 0.5);
+                if (dist < minDist) {
+                    minDist = dist;
+                    bestVar = i;
+                    bestValue = vals[i];
+                }
+            }
+        }
+        if (bestVar < 0) {  // integer node :1070-1076
+            bb_release_node(b, nid);
+            continue;
+        }
+        const int upperInt = (int)std::ceil(bestValue);   // :870-871
+        const int lowerInt = (int)std::floor(bestValue);
+
+        // both children in one batch: lower (<= floor, :1083-1148), upper (>= ceil, :1150-1208)
+        int32_t parents[2] = {nid, nid};
+        int32_t vars[2] = {bestVar, bestVar};
+        double bounds[2] = {(double)lowerInt, (double)upperInt};
+        int32_t kinds[2] = {0, 1};
+        int32_t child[2] = {-1, -1}, cst[2] = {0, 0}, cpiv[2] = {0, 0};
+        std::vector<int32_t> tr, off;
+        rc = bb_expand(b, 2, parents, vars, bounds, kinds, child, cst, cpiv, &tr, &off);
+        if (rc != LPR_OK_OPTIMAL) {
+            if (rc == LPR_BB_NODE_CAP) { status = rc; break; }
+            return rc;
+        }
+        Item kids[2];
+        int nk = 0;
+        for (int side = 0; side < 2; ++side) {
+            const int rid = (int)b->records.size();
+            for (int q = off[side]; q < off[side + 1]; q += 3) {
+                b->piv_trace.push_back(rid);
+                b->piv_trace.push_back(tr[q]);
+                b->piv_trace.push_back(tr[q + 1]);
+                b->piv_trace.push_back(tr[q + 2]);
+            }
+            if (cst[side] == kBBSolved) {
+                int32_t cid = child[side];
+                double cz = 0;
+                std::vector<double> cv((size_t)(n > 0 ? n : 1));
+                rc = bb_node_info(b, &cid, 1, &cz, cv.data());
+                if (rc != LPR_OK_OPTIMAL) return rc;
+                b->records.push_back({it.rec, side + 1, it.depth + 1, bestVar, 0, bounds[side], cz});
+                kids[nk++] = {cid, it.depth + 1, rid};
+            } else {
+                const int st2 = cst[side] == kBBInfeasible ? 1 : 2;
+                b->records.push_back({it.rec, side + 1, it.depth + 1, bestVar, st2, bounds[side],
+                                      0.0});
+            }
+        }
+        for (int k = nk - 1; k >= 0; --k) stack.push_back(kids[k]);  // :1210-1213
+        bb_release_node(b, nid);
+    }
+    for (const Item& it : stack) bb_release_node(b, it.node);
+
+    if (x && b->found)
+        for (int i = 0; i < n; ++i) x[i] = b->best_x[i];
+    res->status = status;
+    res->found = b->found ? 1 : 0;
+    res->processed = processed;
+    res->best_node = b->best_node;
+    res->reserved = 0;
+    res->z = b->best_z;
+    res->pivots = b->total_pivots;
+    res->nodes_created = (int64_t)b->records.size();
+    return status;
+}
+
+int lpr_bb_records_read(lpr_bb* b, int32_t* parent, int32_t* kind, int32_t* depth, int32_t* var,
+                        double* bound, int32_t* status, double* z, int64_t cap, int64_t* count) {
+    if (!b || !count || cap < 0) return LPR_BAD_ARGUMENT;
+    int64_t k = (int64_t)b->records.size();
+    if (k > cap) k = cap;
+    *count = k;
+    for (int64_t q = 0; q < k; ++q) {
+        const lpr_bb::Rec& r = b->records[q];
+        if (parent) parent[q] = r.parent;
+        if (kind) kind[q] = r.kind;
+        if (depth) depth[q] = r.depth;
+        if (var) var[q] = r.var;
+        if (bound) bound[q] = r.bound;
+        if (status) status[q] = r.status;
+        if (z) z[q] = r.z;
+    }
+    return LPR_OK_OPTIMAL;
+}
+
+int lpr_bb_pop_order_read(lpr_bb* b, int32_t* ids, int64_t cap, int64_t* count) {
+    if (!b || !count || cap < 0) return LPR_BAD_ARGUMENT;
+    int64_t k = (int64_t)b->pop_order.size();
+    if (k > cap) k = cap;
+    *count = k;
+    for (int64_t q = 0; q < k; ++q)
+        if (ids) ids[q] = b->pop_order[q];
+    return LPR_OK_OPTIMAL;
+}
+
+int lpr_bb_trace_read(lpr_bb* b, int32_t* quads, int64_t cap, int64_t* count) {
+    if (!b || !count || cap < 0) return LPR_BAD_ARGUMENT;
+    int64_t k = (int64_t)b->piv_trace.size() / 4;
+    if (k > cap) k = cap;
+    *count = k;
+    if (quads) std::memcpy(quads, b->piv_trace.data(), (size_t)k * 4 * sizeof(int32_t));
+    return LPR_OK_OPTIMAL;
+}
+
+}  // extern "C"

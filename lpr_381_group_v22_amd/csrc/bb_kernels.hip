@@ -1,0 +1,595 @@
+// bb_kernels.hip -- gfx950 kernels of the Branch & Bound LP-relaxation path
+// (reference: LPR_381_Group_V22/IntegerProgramming/BranchBoundSimplexSolver.cs).
+//
+// All kernels are batched: blockIdx.z (or .y / .x where noted) is the child sub-problem ("slot") of
+// the current batch, so the two children of a DFS node -- or the whole frontier of a level -- are
+// evaluated by the same launches.  Every node tableau lives in a rows_cap x ld buffer in HBM, ld a
+// multiple of 16 doubles.
+//
+//   k_bb_child_init    AddConstraint, first half (:701-747): round, insert the slack column,
+//                      append the branching row, round again
+//   k_bb_basic_scan    IdentifyBasicVariables (:642-663): rounded column sums, row of the first 1.0
+//   k_bb_eliminate     IdentifyBasicVariables ordering (:665-690) + the sequential eliminations of
+//                      AddConstraint (:752-797)
+//   k_bb_round(_clean) RoundTableau (:552-567) (+ the -0 -> +0 pass of DoDualSimplex :307-313)
+//   k_bb_select        one DoDualSimplex loop head (:305-400): phase logic, PerformDualPivot
+//                      (:115-160) / PerformPrimalPivot (:203-253) selection, pivot row normalise
+//   k_bb_update        the out-of-place row elimination of both pivots (:174-192, :255-271)
+//   k_bb_node_info     GetObjective (:892-897) + decision values (:807-827 / :899-921)
+#include "bb_common.hpp"
+
+#pragma clang fp contract(off)
+
+namespace lpr {
+
+constexpr double kBBEps = 1e-6;  // BranchAndBound.epsilon (:493)
+
+// ------------------------------------------------------------------ .NET Framework rounding
+// Math.Round(double) -- COMDouble::Round (round half to even through floor(x + 0.5)).
+__device__ __forceinline__ double dn_round_int(double x) {
+    if (isnan(x) || isinf(x)) return x;
+    if (fabs(x) < 9.2e18 && x == (double)((long long)x)) return x;
+    const double t = x + 0.5;
+    double f = floor(t);
+    if (f == t && fmod(t, 2.0) != 0) f -= 1.0;
+    return copysign(f, x);
+}
+// Math.Round(double, 4) -- Math.InternalRound: scale, round, unscale; identity for |x| >= 1e16.
+__device__ __forceinline__ double dn_round4(double x) {
+    if (fabs(x) < 1e16) {
+        x = x * 10000.0;
+        x = dn_round_int(x);
+        x = x / 10000.0;
+    }
+    return x;
+}
+
+// ------------------------------------------------------------------ reductions
+struct Cand {
+    double v;
+    int i;
+};
+__device__ __forceinline__ Cand cand_min(Cand a, Cand b) {
+    if (b.i < 0) return a;
+    if (a.i < 0) return b;
+    if (b.v < a.v || (b.v == a.v && b.i < a.i)) return b;
+    return a;
+}
+__device__ __forceinline__ Cand block_cand_min(Cand c, double* lds_v, int* lds_i) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    const int nwaves = blockDim.x / kWave;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        Cand o;
+        o.v = __shfl_xor(c.v, off, kWave);
+        o.i = __shfl_xor(c.i, off, kWave);
+        c = cand_min(c, o);
+    }
+    __syncthreads();
+    if (lane == 0) {
+        lds_v[wave] = c.v;
+        lds_i[wave] = c.i;
+    }
+    __syncthreads();
+    Cand r;
+    r.v = lds_v[0];
+    r.i = lds_i[0];
+    for (int w = 1; w < nwaves; ++w) {
+        Cand o;
+        o.v = lds_v[w];
+        o.i = lds_i[w];
+        r = cand_min(r, o);
+    }
+    return r;
+}
+__device__ __forceinline__ int block_min_int(int v, int* lds) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    const int nwaves = blockDim.x / kWave;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, kWave));
+    __syncthreads();
+    if (lane == 0) lds[wave] = v;
+    __syncthreads();
+    int r = lds[0];
+    for (int w = 1; w < nwaves; ++w) r = min(r, lds[w]);
+    return r;
+}
+
+// ------------------------------------------------------------------ AddConstraint, part 1
+// grid (ceil(ld/256), rows_max_child, nslots).  Child tableau = parent with a zero column inserted
+// before the RHS (:716-719) and the branching row appended (:721-744); every value goes through
+// RoundNumber as often as the C# applies it (working = Round(base) :702, updated = Round(updated)
+// :747).
+__global__ __launch_bounds__(256) void k_bb_child_init(const BBSlot* __restrict__ slots, int ld) {
+    const BBSlot& s = slots[blockIdx.z];
+    const int Rc = s.rows, Cc = s.cols;
+    const int R = Rc - 1, C = Cc - 1;  // parent shape
+    const int i = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Rc || j >= ld) return;
+    const double* __restrict__ P = s.parent;
+    double v = 0.0;
+    if (i < R) {
+        if (j < C - 1) v = dn_round4(dn_round4(P[(size_t)i * ld + j]));
+        else if (j == C) v = dn_round4(dn_round4(P[(size_t)i * ld + (C - 1)]));
+        // j == C - 1: the inserted 0.0; j > C: padding
+    } else {
+        if (j == s.var) v = 1.0;                            // RoundNumber(1) twice is 1
+        if (j == C) v = dn_round4(dn_round4(s.bound));      // :732
+        if (j == C - 1) v = s.reverse ? -1.0 : 1.0;         // slackPosition :734-742
+    }
+    s.cur[(size_t)i * ld + j] = v;
+}
+
+// grid (ceil(C/64), nslots).  One lane per OLD column k: rounded values summed in row order
+// (Enumerable.Sum), |Round(sum) - 1| <= eps marks it "basic" (:657-661); key = row of the first
+// value that is exactly 1.0, else the row count (:680).
+__global__ __launch_bounds__(64) void k_bb_basic_scan(const BBSlot* __restrict__ slots, int ld,
+                                                     int32_t* __restrict__ bflag,
+                                                     int32_t* __restrict__ bkey) {
+    const BBSlot& s = slots[blockIdx.y];
+    const int R = s.rows - 1, C = s.cols - 1;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= C) return;
+    const double* __restrict__ P = s.parent;
+    double sum = 0.0;
+    int key = R;
+    for (int i = 0; i < R; ++i) {
+        const double w = dn_round4(P[(size_t)i * ld + k]);  // working = Round(base) :702
+        const double v = dn_round4(w);                      // RoundNumber inside Identify :655
+        sum = sum + v;
+        if (key == R && v == 1.0) key = i;
+    }
+    sum = dn_round4(sum);
+    bflag[(size_t)blockIdx.y * ld + k] = (fabs(sum - 1.0) <= kBBEps) ? 1 : 0;
+    bkey[(size_t)blockIdx.y * ld + k] = key;
+}
+
+// grid (nslots), one workgroup per child.  Orders the basic columns as
+// OrderBy(first-1.0 row) does (stable: ties by column), then applies the eliminations of :756-796
+// one basic column after the other -- each step reads the coefficient the previous steps left in
+// the new row, so the steps are sequential; inside a step the row is updated in parallel.
+// NOTE the C# indexes the widened tableau with the OLD column numbers (the RHS column index now
+// names the inserted slack column); restated as is.
+__global__ __launch_bounds__(1024) void k_bb_eliminate(const BBSlot* __restrict__ slots, int ld,
+                                                       const int32_t* __restrict__ bflag,
+                                                       const int32_t* __restrict__ bkey,
+                                                       int32_t* __restrict__ blist) {
+    __shared__ int lds[16];
+    __shared__ int s_count;
+    const BBSlot& s = slots[blockIdx.x];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int Rc = s.rows, Cc = s.cols;
+    const int R = Rc - 1, C = Cc - 1;
+    const int crow = R;
+    const int32_t* __restrict__ flag = bflag + (size_t)blockIdx.x * ld;
+    const int32_t* __restrict__ key = bkey + (size_t)blockIdx.x * ld;
+    int32_t* __restrict__ list = blist + (size_t)blockIdx.x * ld;
+    double* __restrict__ T = s.cur;
+    if (tid == 0) s_count = 0;
+    __syncthreads();
+    for (int k = tid; k < C; k += nt) {
+        if (!flag[k]) continue;
+        int rank = 0;
+        const int mykey = key[k];
+        for (int k2 = 0; k2 < C; ++k2)
+            if (flag[k2] && (key[k2] < mykey || (key[k2] == mykey && k2 < k))) ++rank;
+        list[rank] = k;
+        atomicAdd(&s_count, 1);
+    }
+    __syncthreads();
+    const int count = s_count;
+    const int reverse = s.reverse;
+    for (int q = 0; q < count; ++q) {
+        const int colIndex = list[q];
+        const double coefficient = dn_round4(T[(size_t)crow * ld + colIndex]);  // :758
+        if (fabs(coefficient) > kBBEps) {
+            int first = INT_MAX;
+            for (int row = tid; row < R; row += nt)
+                if (fabs(dn_round4(T[(size_t)row * ld + colIndex]) - 1.0) <= kBBEps) {
+                    first = row;
+                    break;
+                }
+            const int pivotRow = block_min_int(first, lds);  // :763-770
+            if (pivotRow != INT_MAX) {
+                for (int col = tid; col < Cc; col += nt) {
+                    const double pivotVal = dn_round4(T[(size_t)pivotRow * ld + col]);
+                    const double constraintVal = dn_round4(T[(size_t)crow * ld + col]);
+                    double newVal;
+                    if (reverse) {
+                        const double prod = coefficient * constraintVal;
+                        newVal = pivotVal - prod;  // :785
+                    } else {
+                        const double prod = coefficient * pivotVal;
+                        newVal = constraintVal - prod;  // :789
+                    }
+                    T[(size_t)crow * ld + col] = dn_round4(newVal);  // :792
+                }
+            }
+        }
+        __syncthreads();  // the next coefficient is read from the row just rewritten
+    }
+}
+
+// grid (ceil(ld/256), rows_max, nslots).  RoundTableau over slot.cur; `clean` adds the
+// `if (x == -0.0) x = 0.0` pass DoDualSimplex applies to the tableau it is handed (:307-313).
+__global__ __launch_bounds__(256) void k_bb_round(const BBSlot* __restrict__ slots, int ld,
+                                                  int clean) {
+    const BBSlot& s = slots[blockIdx.z];
+    const int i = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= s.rows || j >= s.cols) return;
+    double v = dn_round4(s.cur[(size_t)i * ld + j]);
+    if (clean && v == 0.0) v = 0.0;
+    s.cur[(size_t)i * ld + j] = v;
+}
+
+// ------------------------------------------------------------------ DoDualSimplex loop head
+// grid (nslots).  State machine of :305-400 for one child; see bb_common.hpp for the states.
+__global__ __launch_bounds__(1024) void k_bb_select(BBSlot* slots, double* __restrict__ rowbuf_all,
+                                                    double* __restrict__ colbuf_all, int ld,
+                                                    int rows_cap, int32_t* __restrict__ trace_all,
+                                                    int trace_cap, int32_t* running) {
+    __shared__ double lds_v[16];
+    __shared__ int lds_i[16];
+    BBSlot* sp = &slots[blockIdx.x];
+    const int tid = threadIdx.x, nt = blockDim.x;
+
+    // snapshot the header (thread 0 rewrites it at the end)
+    double* cur = sp->cur;
+    double* nxt = sp->nxt;
+    int state = sp->state;
+    int pivots = sp->pivots;
+    int trace_n = sp->trace_n;
+    const int had_update = sp->do_update;
+    const int R = sp->rows, C = sp->cols;
+    __syncthreads();
+    if (had_update) {  // the previous k_bb_update wrote the new tableau into nxt
+        double* t = cur;
+        cur = nxt;
+        nxt = t;
+    }
+    if (state >= kBBSolved) {
+        if (tid == 0 && had_update) {
+            sp->cur = cur;
+            sp->nxt = nxt;
+            sp->do_update = 0;
+        }
+        return;
+    }
+    const int old_state = state;
+    double* __restrict__ rowbuf = rowbuf_all + (size_t)blockIdx.x * ld;
+    double* __restrict__ colbuf = colbuf_all + (size_t)blockIdx.x * rows_cap;
+    int do_update = 0, pr = -1, pc = -1;
+    int tr_phase = -1;  // trace entry to append: 0 dual, 1 primal, 2 "last tableau dropped"
+    const int rhs = C - 1;
+
+    if (state == kBBDual) {
+        int bad = 0;  // !rhsValues.All(num => num >= -1e-9)   (row 0 included, :315-320)
+        for (int i = tid; i < R; i += nt)
+            if (!(cur[(size_t)i * ld + rhs] >= -1e-9)) bad = 1;
+        bad = __syncthreads_or(bad);
+        if (!bad) {
+            int notopt = 0;  // :345-348
+            for (int j = tid; j < C - 1; j += nt)
+                if (!(cur[j] >= 0)) notopt = 1;
+            notopt = __syncthreads_or(notopt);
+            state = notopt ? kBBPrimal : kBBSolved;  // optimal here skips the :351 block entirely
+        } else {
+            // ---- PerformDualPivot :115-160 ----
+            Cand c;
+            c.v = 0.0;
+            c.i = -1;
+            for (int i = tid; i < R; i += nt) {
+                const double x = cur[(size_t)i * ld + rhs];
+                if (x < 0 && (c.i < 0 || x < c.v)) {  // Min() of the negatives, first IndexOf
+                    c.v = x;
+                    c.i = i;
+                }
+            }
+            c = block_cand_min(c, lds_v, lds_i);
+            pr = c.i;
+            if (pr < 0) {
+                state = kBBInfeasible;  // `if (!negativeRhs.Any()) return (tableau, null)` :120
+            } else {
+                const double* __restrict__ prow = cur + (size_t)pr * ld;
+                int non0inf = 0;
+                Cand m;  // lexicographic min over theta > 0: the minimum and its first index
+                m.v = 0.0;
+                m.i = -1;
+                for (int j = tid; j < C - 1; j += nt) {
+                    const double a = prow[j];
+                    const double th = (a < 0) ? fabs(cur[j] / a) : INFINITY;  // :126-143
+                    if (!(th == 0 || th == INFINITY)) non0inf = 1;
+                    if (th > 0 && (m.i < 0 || th < m.v)) {
+                        m.v = th;
+                        m.i = j;
+                    }
+                }
+                non0inf = __syncthreads_or(non0inf);
+                m = block_cand_min(m, lds_v, lds_i);
+                if (!non0inf) {  // every theta is 0 or +inf -> minPositiveTheta = 0 (:146-147)
+                    int first = INT_MAX;
+                    for (int j = tid; j < C - 1; j += nt) {
+                        const double a = prow[j];
+                        const double th = (a < 0) ? fabs(cur[j] / a) : INFINITY;
+                        if (th == 0) {
+                            first = j;
+                            break;
+                        }
+                    }
+                    first = block_min_int(first, lds_i);
+                    pc = (first == INT_MAX) ? -1 : first;
+                } else {
+                    pc = m.i;  // -1: Where(x > 0) empty -> +inf -> IndexOf misses (:148,:154)
+                }
+                if (pc < 0) {
+                    state = kBBInfeasible;  // tableau[rowIndex][-1] throws -> (tableau, null)
+                } else {
+                    do_update = 1;
+                    tr_phase = 0;
+                }
+            }
+        }
+    }
+
+    if (state == kBBPrimal && !do_update) {
+        int need_post = 0;
+        int notopt = 0;  // :368-374
+        for (int j = tid; j < C - 1; j += nt)
+            if (!(cur[j] >= 0)) notopt = 1;
+        notopt = __syncthreads_or(notopt);
+        if (!notopt) {
+            need_post = 1;
+        } else {
+            // ---- PerformPrimalPivot :203-253 (isMinimization == false) ----
+            Cand c;
+            c.v = 0.0;
+            c.i = -1;
+            for (int j = tid; j < C - 1; j += nt) {
+                const double x = cur[j];
+                if (x < 0 && x != 0 && (c.i < 0 || x < c.v)) {
+                    c.v = x;
+                    c.i = j;
+                }
+            }
+            c = block_cand_min(c, lds_v, lds_i);
+            pc = c.i;  // first occurrence of the minimum (IndexOf over the whole row, :220)
+            int fail = (pc < 0);
+            if (!fail) {
+                int notneg = 0, anypos = 0, has0 = 0;
+                Cand m;
+                m.v = 0.0;
+                m.i = -1;
+                for (int i = 1 + tid; i < R; i += nt) {
+                    const double a = cur[(size_t)i * ld + pc];
+                    const double th = (a != 0) ? cur[(size_t)i * ld + rhs] / a : INFINITY;
+                    if (!(th < 0)) notneg = 1;
+                    if (th == 0) has0 = 1;
+                    if (th > 0 && th != INFINITY) {
+                        anypos = 1;
+                        if (m.i < 0 || th < m.v) {
+                            m.v = th;
+                            m.i = i;
+                        }
+                    }
+                }
+                notneg = __syncthreads_or(notneg);
+                anypos = __syncthreads_or(anypos);
+                has0 = __syncthreads_or(has0);
+                m = block_cand_min(m, lds_v, lds_i);
+                if (!notneg) {
+                    fail = 1;  // thetas.All(num => num < 0) (true for an empty list) :228-231
+                } else if (!anypos) {
+                    if (has0) {  // minTheta = 0.0 -> first theta equal to 0 (:236-237,:249)
+                        int first = INT_MAX;
+                        for (int i = 1 + tid; i < R; i += nt) {
+                            const double a = cur[(size_t)i * ld + pc];
+                            const double th = (a != 0) ? cur[(size_t)i * ld + rhs] / a : INFINITY;
+                            if (th == 0) {
+                                first = i;
+                                break;
+                            }
+                        }
+                        first = block_min_int(first, lds_i);
+                        pr = first;
+                    } else {
+                        fail = 1;
+                    }
+                } else {
+                    pr = m.i;
+                }
+                if (!fail && cur[(size_t)pr * ld + pc] == 0) fail = 1;  // :252
+            }
+            if (fail) {
+                need_post = 1;  // thetaCol == null -> NullReferenceException -> catch -> break
+                pr = pc = -1;
+            } else {
+                do_update = 1;
+                tr_phase = 1;
+            }
+        }
+        if (need_post) {  // :392-400
+            int bad = 0;
+            for (int i = tid; i < R; i += nt)
+                if (!(cur[(size_t)i * ld + rhs] >= 0)) bad = 1;
+            bad = __syncthreads_or(bad);
+            if (bad) {
+                if (pivots == 0) {
+                    state = kBBFailed;  // pivotColumns.RemoveAt(-1) throws
+                } else {
+                    double* t = cur;  // tableaux.RemoveAt(Count - 1): back to the previous one
+                    cur = nxt;
+                    nxt = t;
+                    pivots -= 1;
+                    tr_phase = 2;
+                    state = kBBSolved;
+                }
+            } else {
+                state = kBBSolved;
+            }
+        }
+    }
+
+    if (do_update) {  // normalised pivot row (:174-178 / :257-261) and the factor column
+        const double p = cur[(size_t)pr * ld + pc];
+        const double* __restrict__ prow = cur + (size_t)pr * ld;
+        for (int j = tid; j < ld; j += nt) {
+            double v = (j < C) ? prow[j] / p : 0.0;
+            if (v == 0.0) v = 0.0;  // `== -0.0` is true for both zeros
+            rowbuf[j] = v;
+        }
+        for (int i = tid; i < R; i += nt) colbuf[i] = cur[(size_t)i * ld + pc];
+        pivots += 1;
+    }
+
+    if (tid == 0) {
+        if (tr_phase >= 0) {
+            if (trace_n < trace_cap) {
+                int32_t* tr = trace_all + ((size_t)blockIdx.x * trace_cap + trace_n) * 3;
+                tr[0] = tr_phase;
+                tr[1] = (tr_phase == 2) ? -1 : pr;
+                tr[2] = (tr_phase == 2) ? -1 : pc;
+            }
+            trace_n += 1;
+        }
+        sp->cur = cur;
+        sp->nxt = nxt;
+        sp->state = state;
+        sp->pivots = pivots;
+        sp->pr = pr;
+        sp->pc = pc;
+        sp->do_update = do_update;
+        sp->trace_n = trace_n;
+        if (old_state < kBBSolved && state >= kBBSolved) atomicSub(running, 1);
+    }
+}
+
+__device__ __forceinline__ int align_up_dev(int x) { return (x + kLdAlign - 1) / kLdAlign * kLdAlign; }
+
+// grid (ceil(ld2/256), ceil(rows_max/TR), nslots).  Out-of-place like the C# (a fresh tableau per
+// pivot): nxt = cur - colbuf (x) rowbuf, the pivot row replaced by the normalised one, every value
+// passed through the -0 -> +0 rule the C# applies to each new tableau (:334-340, :355-361).
+template <int TR>
+__global__ __launch_bounds__(256) void k_bb_update(const BBSlot* __restrict__ slots,
+                                                   const double* __restrict__ rowbuf_all,
+                                                   const double* __restrict__ colbuf_all, int ld,
+                                                   int rows_cap) {
+    const BBSlot& s = slots[blockIdx.z];
+    if (!s.do_update) return;
+    const int ld2 = ld >> 1;
+    const int c2 = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i0 = blockIdx.y * TR;
+    if (c2 >= ld2 || i0 >= s.rows) return;
+    if (2 * c2 >= align_up_dev(s.cols)) return;  // nothing but padding beyond
+    const double2 pr = reinterpret_cast<const double2*>(rowbuf_all + (size_t)blockIdx.z * ld)[c2];
+    const double* __restrict__ colbuf = colbuf_all + (size_t)blockIdx.z * rows_cap;
+    const double2* __restrict__ in = reinterpret_cast<const double2*>(s.cur);
+    double2* __restrict__ out = reinterpret_cast<double2*>(s.nxt);
+    const int r = s.pr;
+    double2 x[TR];
+#pragma unroll
+    for (int k = 0; k < TR; ++k)
+        if (i0 + k < s.rows) x[k] = in[(size_t)(i0 + k) * ld2 + c2];
+#pragma unroll
+    for (int k = 0; k < TR; ++k) {
+        const int i = i0 + k;
+        if (i < s.rows) {
+            const double f = colbuf[i];
+            const double px = f * pr.x;
+            const double py = f * pr.y;
+            double2 o;
+            o.x = x[k].x - px;
+            o.y = x[k].y - py;
+            if (i == r) o = pr;
+            if (o.x == 0.0) o.x = 0.0;
+            if (o.y == 0.0) o.y = 0.0;
+            out[(size_t)i * ld2 + c2] = o;
+        }
+    }
+}
+
+// grid (ceil(nvars/64), count).  info[slot] = { z, x_0 .. x_{nvars-1} }: GetObjective (:892-897)
+// and the "first row whose rounded entry is 1" decision values (:807-827, :899-921; row 0 is
+// part of the scan).
+__global__ __launch_bounds__(64) void k_bb_node_info(const BBSlot* __restrict__ slots, int ld,
+                                                    int nvars, double* __restrict__ info) {
+    const BBSlot& s = slots[blockIdx.y];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const double* __restrict__ T = s.cur;
+    const int R = s.rows, C = s.cols;
+    double* out = info + (size_t)blockIdx.y * (nvars + 1);
+    if (i == 0) out[0] = dn_round4(T[C - 1]);
+    if (i >= nvars) return;
+    double val = 0.0;
+    for (int j = 0; j < R; ++j) {
+        const double v = dn_round4(T[(size_t)j * ld + i]);
+        if (fabs(v - 1.0) <= kBBEps) {
+            val = dn_round4(T[(size_t)j * ld + (C - 1)]);
+            break;
+        }
+    }
+    out[1 + i] = val;
+}
+
+// copies a (rows x cols, leading dimension src_ld) matrix into a node buffer (ld), zero padding
+__global__ __launch_bounds__(256) void k_bb_copy_in(const double* __restrict__ src, int src_ld,
+                                                    int rows, int cols, double* __restrict__ dst,
+                                                    int ld) {
+    const int i = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows || j >= ld) return;
+    dst[(size_t)i * ld + j] = (j < cols) ? src[(size_t)i * src_ld + j] : 0.0;
+}
+
+// ------------------------------------------------------------------ launchers
+
+void bb_launch_copy_in(lpr_bb* b, const double* src, int src_ld, int rows, int cols, double* dst) {
+    hipLaunchKernelGGL(k_bb_copy_in, dim3((b->ld + 255) / 256, rows), dim3(256), 0, b->eng->stream,
+                       src, src_ld, rows, cols, dst, b->ld);
+}
+
+void bb_launch_round(lpr_bb* b, int nslots, int rows_max, int clean) {
+    hipLaunchKernelGGL(k_bb_round, dim3((b->ld + 255) / 256, rows_max, nslots), dim3(256), 0,
+                       b->eng->stream, b->d_slots, b->ld, clean);
+}
+
+void bb_launch_node_info(lpr_bb* b, int count) {
+    hipLaunchKernelGGL(k_bb_node_info, dim3((b->nvars + 63) / 64 > 0 ? (b->nvars + 63) / 64 : 1,
+                                            count),
+                       dim3(64), 0, b->eng->stream, b->d_slots, b->ld, b->nvars, b->info);
+}
+
+void bb_launch_add_constraint(lpr_bb* b, int nslots, int rows_max, int cols_max) {
+    hipStream_t st = b->eng->stream;
+    hipLaunchKernelGGL(k_bb_child_init, dim3((b->ld + 255) / 256, rows_max, nslots), dim3(256), 0,
+                       st, b->d_slots, b->ld);
+    hipLaunchKernelGGL(k_bb_basic_scan, dim3((cols_max + 63) / 64, nslots), dim3(64), 0, st,
+                       b->d_slots, b->ld, b->bflag, b->bkey);
+    hipLaunchKernelGGL(k_bb_eliminate, dim3(nslots), dim3(1024), 0, st, b->d_slots, b->ld,
+                       b->bflag, b->bkey, b->blist);
+    hipLaunchKernelGGL(k_bb_round, dim3((b->ld + 255) / 256, rows_max, nslots), dim3(256), 0, st,
+                       b->d_slots, b->ld, 1);  // :799 + the clean of :307-313
+}
+
+void bb_launch_pivot_step(lpr_bb* b, int nslots, int rows_max, int cols_max) {
+    hipStream_t st = b->eng->stream;
+    const int threads = (rows_max > 256 || cols_max > 256) ? 1024 : 256;
+    hipLaunchKernelGGL(k_bb_select, dim3(nslots), dim3(threads), 0, st, b->d_slots, b->rowbuf,
+                       b->colbuf, b->ld, b->rows_cap, b->trace, b->trace_cap, b->d_running);
+    constexpr int TR = 4;
+    const int ld2 = align_up(cols_max, kLdAlign) / 2;
+    hipLaunchKernelGGL((k_bb_update<TR>), dim3((ld2 + 255) / 256, (rows_max + TR - 1) / TR, nslots),
+                       dim3(256), 0, st, b->d_slots, b->rowbuf, b->colbuf, b->ld, b->rows_cap);
+}
+
+void bb_launch_select_only(lpr_bb* b, int nslots, int rows_max, int cols_max) {
+    const int threads = (rows_max > 256 || cols_max > 256) ? 1024 : 256;
+    hipLaunchKernelGGL(k_bb_select, dim3(nslots), dim3(threads), 0, b->eng->stream, b->d_slots,
+                       b->rowbuf, b->colbuf, b->ld, b->rows_cap, b->trace, b->trace_cap,
+                       b->d_running);
+}
+
+}  // namespace lpr

@@ -59,6 +59,7 @@ struct PivotState {
 
 struct lpr_tableau;
 struct lpr_revised;
+struct lpr_bb;
 
 struct lpr_engine {
     int device = 0;
@@ -69,6 +70,7 @@ struct lpr_engine {
     // device memory and orphans them so that a late lpr_tableau_destroy stays safe
     std::vector<lpr_tableau*> live;
     std::vector<lpr_revised*> live_rev;
+    std::vector<lpr_bb*> live_bb;
 };
 
 struct lpr_tableau {

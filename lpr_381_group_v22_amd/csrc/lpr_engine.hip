@@ -36,6 +36,8 @@ void launch_synthetic(lpr_tableau* t, int m, int n, uint64_t seed);
 
 // revised_engine.hip
 void rev_orphan(lpr_revised* s);
+// bb_engine.hip
+void bb_orphan(lpr_bb* b);
 
 enum : int { kSelEnter = 1, kSelLeave = 2, kSelCommit = 4, kSelFull = 7 };
 constexpr int kTimeStride = 4;  // opts.time_kernels samples one update launch in four
@@ -224,6 +226,8 @@ int lpr_engine_close(lpr_engine* e) {
     e->live.clear();
     for (lpr_revised* r : e->live_rev) rev_orphan(r);
     e->live_rev.clear();
+    for (lpr_bb* b : e->live_bb) bb_orphan(b);
+    e->live_bb.clear();
     if (e->stream) {
         hipStreamSynchronize(e->stream);
         hipStreamDestroy(e->stream);
