@@ -124,7 +124,9 @@ def main() -> int:
                     "frac": round(achieved / HBM_PEAK_GBPS, 4),
                     "bytes_per_launch": bytes_per_pivot,
                     "avg_launch_ms": round(kern_ms, 6), "launches": launches,
+                    "event_sampling": "every 4th k_update launch of the timed region",
                     "traffic": None}
+            roof.update(_pmc_traffic(m, n))
         cpu = None
         if world == 1 and args.cpu_pivots != 0:
             cp = args.cpu_pivots
@@ -161,6 +163,25 @@ def main() -> int:
     if out is not None:
         print(json.dumps(out), flush=True)
     return 0
+
+
+def _pmc_traffic(m: int, n: int) -> dict:
+    """HBM-side bytes of one k_update launch from the rocprofv3 PMC passes (FETCH_SIZE doubled for
+    gfx950 wide reads + WRITE_SIZE, separate --pmc runs).  Counters cannot be read from inside the
+    process, so the newest summary committed under profiles/ for this workload is reported."""
+    import glob
+    best = {}
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_pmc_summary.json"))):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            t = d.get("k_update_traffic_per_launch", {})
+            if t.get("algorithmic_bytes") == 2 * 8 * (m + 1) * (n + m + 1):
+                best = {"traffic": int(t["hbm_side_bytes"]),
+                        "traffic_source": os.path.relpath(path, ROOT)}
+        except (OSError, ValueError, KeyError):
+            continue
+    return best
 
 
 def _cpu_model() -> str:

@@ -1,0 +1,165 @@
+// GpuSolvers.cs -- drop-in bodies for the three solver classes of LPR_381_Group_V22, calling the
+// MI355X engine through NativeMethods.  UNVERIFIED (never compiled: no C# toolchain in the build
+// image).  Public members, argument meaning and error behaviour are those of the reference classes
+// so that Program.cs (cases "1", "2", "3") compiles unchanged when these replace
+// Simplex/PrimalSimplexSolver.cs, Simplex/RevisedPrimalSimplexSolver.cs and
+// IntegerProgramming/BranchAndBoundAdapter.cs.
+using System;
+using System.Collections.Generic;
+using System.Linq;
+using LPR_381_Group_V22.Native;
+using LPR_381_Group_V22.Utilities;
+using IOConstraint = LPR_381_Group_V22.IO.InputFileParser.Constraint;
+
+namespace LPR_381_Group_V22.Simplex
+{
+    public class PrimalSimplexSolver : IDisposable
+    {
+        private readonly int numVariables, numConstraints;
+        internal IntPtr Tableau;                       // lpr_tableau*
+        public List<string> IterationSnapshots = new List<string>();
+        public double FinalZ { get; private set; }
+        public List<double> SolutionVector { get; private set; }
+        public double[,] FinalTableau { get; private set; }
+        /// <summary>Snapshots are O(R*C) text each; off above this many elements.</summary>
+        public static int SnapshotElementLimit = 4096;
+
+        public PrimalSimplexSolver(List<double> objective, List<IOConstraint> constraints, bool isMaximization = true)
+        {
+            numVariables = objective.Count;
+            numConstraints = constraints.Count;
+            int n = numVariables, m = numConstraints;
+            var A = new double[Math.Max(1, m * n)];
+            var ncoef = new int[Math.Max(1, m)];
+            var rel = new sbyte[Math.Max(1, m)];
+            var rhs = new double[Math.Max(1, m)];
+            for (int i = 0; i < m; i++)
+            {
+                int k = Math.Min(n, constraints[i].Coefficients.Count);   // PrimalSimplexSolver.cs:68-72
+                for (int j = 0; j < k; j++) A[i * n + j] = constraints[i].Coefficients[j];
+                ncoef[i] = k;
+                rel[i] = (sbyte)(constraints[i].Relation == ">=" ? 1 : constraints[i].Relation == "=" ? 2 : 0);
+                rhs[i] = constraints[i].RHS;
+            }
+            NativeMethods.ThrowIfError(NativeMethods.lpr_tableau_from_lp(Engine.Handle, n, m, objective.ToArray(), A, n,
+                ncoef, rel, rhs, isMaximization ? 1 : 0, out Tableau), "lpr_tableau_from_lp");
+            if ((long)(m + 1) * (n + m + 1) <= SnapshotElementLimit) CaptureSnapshot("Initial Tableau");
+        }
+
+        public void Solve()
+        {
+            var opts = new LprSolveOpts();
+            NativeMethods.ThrowIfError(NativeMethods.lpr_primal_solve(Tableau, ref opts, out var res), "lpr_primal_solve");
+            if (res.status == (int)LprStatus.Optimal)
+            {
+                var x = new double[Math.Max(1, numVariables)];
+                NativeMethods.lpr_extract_solution(Tableau, numVariables, x, out double z);
+                FinalZ = z;                                            // :113
+                SolutionVector = x.Take(numVariables).ToList();        // :114
+                FinalTableau = GetFinalTableau();                      // :116
+                Console.WriteLine("Optimal Solution Found!");
+            }
+            else if (res.status == (int)LprStatus.Unbounded)
+            {
+                Console.WriteLine("Unbounded Solution!");             // :131, FinalZ stays 0, SolutionVector null
+                FinalTableau = GetFinalTableau();
+            }
+        }
+
+        public double[,] GetFinalTableau()
+        {
+            NativeMethods.lpr_tableau_shape(Tableau, out int r, out int c, out _);
+            var t = new double[r, c];
+            NativeMethods.ThrowIfError(NativeMethods.lpr_tableau_read(Tableau, t), "lpr_tableau_read");
+            return t;
+        }
+
+        public List<int> BasicVariables
+        {
+            get { var b = new int[Math.Max(1, numConstraints)]; NativeMethods.lpr_basis_read(Tableau, b); return b.Take(numConstraints).ToList(); }
+        }
+
+        private void CaptureSnapshot(string title) =>
+            IterationSnapshots.Add(TableIterationFormater.Format(GetFinalTableau(), numVariables, title));
+
+        public void Dispose() { if (Tableau != IntPtr.Zero) { NativeMethods.lpr_tableau_destroy(Tableau); Tableau = IntPtr.Zero; } }
+    }
+
+    public class RevisedPrimalSimplexSolver : IDisposable
+    {
+        private readonly int n, m;
+        private IntPtr solver;
+        public List<string> IterationSnapshots { get; private set; } = new List<string>();
+        public double FinalZ { get; private set; }
+        public List<double> SolutionVector { get; private set; } = new List<double>();
+
+        public RevisedPrimalSimplexSolver(List<double> objective, List<IOConstraint> constraints, bool isMinimization)
+        {
+            if (objective == null || objective.Count == 0) throw new ArgumentException("Objective cannot be null or empty.");
+            if (constraints == null || constraints.Count == 0) throw new ArgumentException("Constraints cannot be null or empty.");
+            n = objective.Count; m = constraints.Count;
+            var A = new double[m, n];
+            var b = new double[m];
+            for (int i = 0; i < m; i++)
+            {
+                if (constraints[i].Coefficients.Count != n)
+                    throw new ArgumentException($"Constraint {i + 1} has incorrect number of coefficients.");
+                for (int j = 0; j < n; j++) A[i, j] = constraints[i].Coefficients[j];
+                b[i] = constraints[i].RHS;
+            }
+            NativeMethods.ThrowIfError(NativeMethods.lpr_revised_create(Engine.Handle, n, m, objective.ToArray(), A, n, b,
+                isMinimization ? 1 : 0, out solver), "lpr_revised_create");
+        }
+
+        public void Solve()
+        {
+            var opts = new LprSolveOpts();
+            NativeMethods.ThrowIfError(NativeMethods.lpr_revised_solve(solver, ref opts, out var res), "lpr_revised_solve");
+            switch ((LprStatus)res.status)
+            {
+                case LprStatus.Optimal:
+                    var x = new double[n];
+                    NativeMethods.lpr_revised_solution(solver, x, out double z);
+                    SolutionVector = x.ToList(); FinalZ = z; break;
+                // the reference's `throw new Exception(...)` texts (RevisedPrimalSimplexSolver.cs:91,179,183,267)
+                case LprStatus.InfeasibleBasis: throw new Exception("Infeasible basis (negative basic value).");
+                case LprStatus.Unbounded: throw new Exception("Unbounded problem (no positive component in direction).");
+                case LprStatus.EnteringAlreadyBasic: throw new Exception("Internal error: entering variable is already basic.");
+                case LprStatus.PivotTooSmall: throw new Exception("Pivot too small.");
+            }
+        }
+
+        public List<int> BasicVariables { get { var b = new int[m]; NativeMethods.lpr_revised_basis_read(solver, b); return b.ToList(); } }
+
+        /// <summary>B^-1 * A of CaptureSnapshot (:360) on the fp64 matrix cores.</summary>
+        public double[,] BInverseTimesA() { var p = new double[m, n]; NativeMethods.lpr_revised_binv_a(solver, p, out _); return p; }
+
+        public void Dispose() { if (solver != IntPtr.Zero) { NativeMethods.lpr_revised_destroy(solver); solver = IntPtr.Zero; } }
+    }
+}
+
+namespace LPR_381_Group_V22.IntegerProgramming
+{
+    using LPR_381_Group_V22.Simplex;
+
+    public static class BranchAndBoundAdapter
+    {
+        public static (List<double> x, double z) SolveFromPrimal(PrimalSimplexSolver primal, bool enablePruning = false, bool isMin = false)
+        {
+            if (primal.FinalTableau == null)
+                throw new InvalidOperationException("Primal simplex has not been solved yet.");   // BranchAndBoundAdapter.cs:11-14
+            int nvars = primal.SolutionVector?.Count ?? Math.Max(1, primal.FinalTableau.GetLength(1) - 1);   // :20
+            // the FinalTableau is still resident on the device: no double[,] -> List<List<double>> conversion
+            NativeMethods.ThrowIfError(NativeMethods.lpr_bb_create_from_tableau(primal.Tableau, nvars, 20, out IntPtr bb), "lpr_bb_create_from_tableau");
+            try
+            {
+                var opts = new LprBbOpts { enable_pruning = enablePruning ? 1 : 0, node_cap = 20 };   // :1038
+                var x = new double[Math.Max(1, nvars)];
+                NativeMethods.ThrowIfError(NativeMethods.lpr_bb_run(bb, ref opts, x, out var res), "lpr_bb_run");
+                if (res.status == (int)LprStatus.BbNodeCap) Console.WriteLine("Potential infinite loop detected");
+                return res.found != 0 ? (x.Take(nvars).ToList(), res.z) : (new List<double>(), double.NegativeInfinity);   // :23
+            }
+            finally { NativeMethods.lpr_bb_destroy(bb); }
+        }
+    }
+}

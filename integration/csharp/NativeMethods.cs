@@ -1,0 +1,118 @@
+// NativeMethods.cs -- P/Invoke binding of include/lpr_engine.h for LPR_381_Group_V22.
+// UNVERIFIED: no C# toolchain exists in the build image, this file has never been compiled.
+// Add it (and the three Gpu*.cs wrappers) to LPR_381_Group_V22.csproj, build x64
+// (<PlatformTarget>x64</PlatformTarget>: the engine is a 64-bit library) and ship liblpr_engine.so
+// (Linux/.NET on ROCm) next to the executable.
+using System;
+using System.Runtime.InteropServices;
+
+namespace LPR_381_Group_V22.Native
+{
+    internal enum LprStatus
+    {
+        Optimal = 0, Unbounded = 1, InfeasibleBasis = 2, PivotTooSmall = 3,
+        EnteringAlreadyBasic = 4, PivotLimit = 5, BbNodeCap = 6,
+        BadArgument = -1, DeviceError = -2, OutOfMemory = -3
+    }
+
+    [StructLayout(LayoutKind.Sequential)]
+    internal struct LprSolveOpts
+    {
+        public long max_pivots; public int time_kernels; public int batch; public int variant; public int reserved;
+    }
+
+    [StructLayout(LayoutKind.Sequential)]
+    internal struct LprSolveResult
+    {
+        public int status; public int reserved; public long pivots; public long total_pivots; public double z;
+    }
+
+    [StructLayout(LayoutKind.Sequential)]
+    internal struct LprRevisedResult
+    {
+        public int status; public int reserved; public long iterations; public long total_iterations; public double z;
+    }
+
+    [StructLayout(LayoutKind.Sequential)]
+    internal struct LprBbOpts
+    {
+        public int enable_pruning; public int node_cap; public int reserved0; public int reserved1;
+    }
+
+    [StructLayout(LayoutKind.Sequential)]
+    internal struct LprBbResult
+    {
+        public int status; public int found; public long processed; public int best_node; public int reserved;
+        public double z; public long pivots; public long nodes_created;
+    }
+
+    internal static class NativeMethods
+    {
+        private const string Lib = "lpr_engine"; // liblpr_engine.so
+        private const CallingConvention CC = CallingConvention.Cdecl;
+
+        [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_abi_version();
+        [DllImport(Lib, CallingConvention = CC)] internal static extern IntPtr lpr_last_error();
+        [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_engine_open(int device, out IntPtr engine);
+        [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_engine_close(IntPtr engine);
+
+        // ---- PrimalSimplexSolver (Simplex/PrimalSimplexSolver.cs) ----
+        [DllImport(Lib, CallingConvention = CC)]
+        internal static extern int lpr_tableau_from_lp(IntPtr engine, int n, int m, double[] objective, double[] A, int lda,
+            int[] ncoef, sbyte[] relation, double[] rhs, int is_max, out IntPtr tableau);
+        [DllImport(Lib, CallingConvention = CC)]
+        internal static extern int lpr_tableau_create(IntPtr engine, int rows, int cols, double[,] rowmajor, int[] basis, out IntPtr tableau);
+        [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_tableau_destroy(IntPtr tableau);
+        [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_tableau_shape(IntPtr tableau, out int rows, out int cols, out int ld);
+        [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_primal_solve(IntPtr tableau, ref LprSolveOpts opts, out LprSolveResult res);
+        [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_select_entering(IntPtr tableau, out int col);
+        [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_select_leaving(IntPtr tableau, int col, out int row);
+        [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_pivot(IntPtr tableau, int row, int col);
+        [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_extract_solution(IntPtr tableau, int n, double[] x, out double z);
+        [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_tableau_read(IntPtr tableau, double[,] rowmajorOut);
+        [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_basis_read(IntPtr tableau, int[] basisOut);
+        [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_pivot_log_read(IntPtr tableau, int[] rows, int[] cols, long cap, out long count);
+
+        // ---- RevisedPrimalSimplexSolver (Simplex/RevisedPrimalSimplexSolver.cs) ----
+        [DllImport(Lib, CallingConvention = CC)]
+        internal static extern int lpr_revised_create(IntPtr engine, int n, int m, double[] objective, double[,] A, int lda, double[] b, int is_min, out IntPtr solver);
+        [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_revised_destroy(IntPtr solver);
+        [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_revised_solve(IntPtr solver, ref LprSolveOpts opts, out LprRevisedResult res);
+        [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_revised_solution(IntPtr solver, double[] x, out double z);
+        [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_revised_basis_read(IntPtr solver, int[] basis);
+        [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_revised_binv_read(IntPtr solver, double[,] binv);
+        [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_revised_xb_read(IntPtr solver, double[] xb);
+        [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_revised_binv_a(IntPtr solver, double[,] product, out double ms);
+
+        // ---- BranchAndBoundAdapter / BranchBoundSimplexSolver ----
+        [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_bb_create_from_tableau(IntPtr tableau, int nvars, int max_depth, out IntPtr bb);
+        [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_bb_create(IntPtr engine, double[,] finalTableau, int rows, int cols, int nvars, int max_depth, out IntPtr bb);
+        [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_bb_run(IntPtr bb, ref LprBbOpts opts, double[] x, out LprBbResult res);
+        [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_bb_destroy(IntPtr bb);
+
+        internal static string LastError() => Marshal.PtrToStringAnsi(lpr_last_error()) ?? "";
+
+        internal static void ThrowIfError(int status, string where)
+        {
+            if (status < 0) throw new InvalidOperationException($"{where}: {(LprStatus)status} -- {LastError()}");
+        }
+    }
+
+    /// <summary>One engine (HIP device 0 + stream) for the process, released at exit.</summary>
+    internal static class Engine
+    {
+        private static IntPtr _handle = IntPtr.Zero;
+        internal static IntPtr Handle
+        {
+            get
+            {
+                if (_handle == IntPtr.Zero)
+                {
+                    NativeMethods.ThrowIfError(NativeMethods.lpr_engine_open(0, out _handle), "lpr_engine_open");
+                    AppDomain.CurrentDomain.ProcessExit += (s, e) => NativeMethods.lpr_engine_close(_handle);
+                }
+                return _handle;
+            }
+        }
+    }
+}
