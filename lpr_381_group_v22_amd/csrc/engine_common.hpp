@@ -24,6 +24,7 @@ namespace lpr {
 constexpr int kWave = 64;
 constexpr int kLdAlign = 16;          // tableau rows padded to 16 doubles = 128 B
 constexpr int32_t kRunning = -100;    // device status word while the pivot loop is live
+constexpr int kMaxHeadGroups = 32;    // k_pivot_head workgroups (partials per bank)
 
 void set_error(const char* fmt, ...);
 const char* get_error();
@@ -50,9 +51,7 @@ struct PivotState {
     int64_t iter;       // pivots performed so far
     int64_t max_iter;   // stop when iter reaches this (<= 0: no limit)
     int64_t log_cap;    // capacity of the pivot log in pairs
-    int32_t next_e;     // entering column of the NEXT pivot, chosen by k_pivot_head from the Z row
-                        // it has just computed in registers (-1: the next tableau is optimal)
-    int32_t pad;
+    int64_t iter_pending;  // iter + 1 once k_pivot_head has chosen a pivot; k_update commits it
 };
 
 }  // namespace lpr
@@ -81,6 +80,7 @@ struct lpr_tableau {
     double* colbuf = nullptr;        // rows doubles: pivot column before the update
     double* next_col = nullptr;      // rows doubles: column next_e of the tableau AFTER the update
     double* next_rhs = nullptr;      // rows doubles: RHS column of the tableau AFTER the update
+    void* zparts = nullptr;          // 2 banks x kMaxHeadGroups partial arg-mins of the next Z row
     int32_t* basis = nullptr;        // rows-1
     int32_t* log = nullptr;          // 2*log_cap: (row, col) pairs
     int64_t log_cap = 0;

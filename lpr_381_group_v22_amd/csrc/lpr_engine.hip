@@ -63,6 +63,7 @@ static int alloc_tableau(lpr_engine* e, int rows, int cols, lpr_tableau** out) {
     chk(hipMalloc(&t->colbuf, (size_t)align_up(rows, 16) * sizeof(double)));
     chk(hipMalloc(&t->next_col, (size_t)align_up(rows, 16) * sizeof(double)));
     chk(hipMalloc(&t->next_rhs, (size_t)align_up(rows, 16) * sizeof(double)));
+    chk(hipMalloc(&t->zparts, (size_t)2 * kMaxHeadGroups * 16));
     chk(hipMalloc(&t->basis, (size_t)(rows > 1 ? rows - 1 : 1) * sizeof(int32_t)));
     chk(hipMalloc(&t->log, (size_t)t->log_cap * 2 * sizeof(int32_t)));
     chk(hipMalloc(&t->state, sizeof(PivotState)));
@@ -108,6 +109,7 @@ static void release_device(lpr_tableau* t) {
     hipFree(t->colbuf);
     hipFree(t->next_col);
     hipFree(t->next_rhs);
+    hipFree(t->zparts);
     hipFree(t->basis);
     hipFree(t->log);
     hipFree(t->state);
@@ -116,6 +118,7 @@ static void release_device(lpr_tableau* t) {
     if (t->h_state) hipHostFree(t->h_state);
     if (t->h_scratch_i) hipHostFree(t->h_scratch_i);
     t->T = t->rowbuf = t->colbuf = t->xbuf = t->next_col = t->next_rhs = nullptr;
+    t->zparts = nullptr;
     t->basis = t->log = t->scratch_i = t->h_scratch_i = nullptr;
     t->state = t->h_state = nullptr;
 }

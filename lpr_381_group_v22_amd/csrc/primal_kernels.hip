@@ -212,14 +212,39 @@ __global__ __launch_bounds__(1024) void k_select(double* __restrict__ T, int ld,
 }
 
 // ------------------------------------------------------------------------------------------
+// Partial results of the next-entering-column arg-min, one per k_pivot_head workgroup.  Two banks,
+// selected by the parity of the pivot counter: head t reads bank (iter & 1) -- written by head t-1
+// or by k_bootstrap -- and writes bank ((iter + 1) & 1), so a fast workgroup can never overwrite a
+// partial that a slow one has not read yet.
+struct ZPart {
+    double v;
+    int32_t i;
+    int32_t pad;
+};
+
+__device__ __forceinline__ Cand reduce_zparts(const ZPart* __restrict__ bank, int G) {
+    Cand c;
+    c.v = 0.0;
+    c.i = -1;
+    for (int p = 0; p < G; ++p) {  // G <= kMaxHeadGroups uniform loads, a line or two of L2
+        Cand o;
+        o.v = bank[p].v;
+        o.i = bank[p].i;
+        c = cand_min(c, o);
+    }
+    return c;
+}
+
+// ------------------------------------------------------------------------------------------
 // k_bootstrap: primes the pipelined loop head.  FindEnteringVariable (:152-167) on the current Z
-// row -> st->next_e, and the strided gather of column next_e and of the RHS column into the dense
-// next_col / next_rhs vectors.  Runs once per lpr_primal_solve call; afterwards k_update keeps
-// those vectors current as a by-product of its sweep.
+// row -> partial 0 of the current bank, and the strided gather of that column and of the RHS column
+// into the dense next_col / next_rhs vectors.  Runs once per lpr_primal_solve call; afterwards
+// k_update keeps those vectors current as a by-product of its sweep.
 __global__ __launch_bounds__(1024) void k_bootstrap(const double* __restrict__ T, int ld, int R,
                                                     int C, double* __restrict__ next_col,
                                                     double* __restrict__ next_rhs,
-                                                    PivotState* st) {
+                                                    PivotState* st, ZPart* __restrict__ zparts,
+                                                    int G) {
     __shared__ double lds_v[16];
     __shared__ int lds_i[16];
     const int tid = threadIdx.x;
@@ -244,7 +269,12 @@ __global__ __launch_bounds__(1024) void k_bootstrap(const double* __restrict__ T
     }
     c = block_cand_min(c, lds_v, lds_i);
     const int e = c.i;
-    if (tid == 0) st->next_e = e;
+    ZPart* bank = zparts + (st->iter & 1) * kMaxHeadGroups;
+    if (tid < G) {
+        bank[tid].v = (tid == 0) ? c.v : 0.0;
+        bank[tid].i = (tid == 0) ? e : -1;
+    }
+    if (tid == 0) st->iter_pending = st->iter;
     if (e < 0) return;
     const int rhs = C - 1;
     for (int i0 = tid; i0 < R; i0 += 4 * nt) {
@@ -268,70 +298,97 @@ __global__ __launch_bounds__(1024) void k_bootstrap(const double* __restrict__ T
 }
 
 // ------------------------------------------------------------------------------------------
-// k_pivot_head: one C# loop head (Solve :107-142) in two memory round trips.
-//   1. e = st->next_e, already chosen (-1 -> optimal, :110-126).
+// k_pivot_head: one C# loop head (Solve :107-142), G workgroups, two memory round trips each.
+//   1. e = arg-min over the G partials of the current bank (-1 -> optimal, :110-126).
 //   2. FindLeavingVariable (:169-191) over the DENSE next_col / next_rhs vectors that the previous
-//      k_update wrote while it streamed the tableau (coalesced, no strided gather); next_col is
-//      also this pivot's factor column (colbuf).
-//   3. Pivot, first half (:195-199): rowbuf = T[r, :] / T[r, e]; at the same time the Z row of the
-//      tableau AFTER this pivot is formed in registers, z'[j] = T[0, j] - (f0 * rowbuf[j]) --
-//      the very expression k_update will store -- and FindEnteringVariable (:152-167) runs on it,
-//      so the NEXT entering column is known before this pivot's update starts and k_update can
+//      k_update wrote while it streamed the tableau (coalesced, no strided gather).  Every
+//      workgroup does this 64 KB scan itself -- cheaper than any cross-workgroup hand-off -- and
+//      all arrive at the same r.  next_col is also this pivot's factor column (colbuf, copied by
+//      workgroup 0).
+//   3. Pivot, first half (:195-199), split by columns over the workgroups (one CU can only pull
+//      ~50 GB/s, the row is 98 KB): rowbuf = T[r, :] / T[r, e]; at the same time the Z row of the
+//      tableau AFTER this pivot is formed in registers, z'[j] = T[0, j] - (f0 * rowbuf[j]) -- the
+//      very expression k_update will store -- and FindEnteringVariable (:152-167) runs on it; each
+//      workgroup publishes its partial arg-min, k_update and the next head reduce the G partials.
+//      So the NEXT entering column is known before this pivot's update starts and k_update can
 //      dump that column on the fly.
-// MAXC2 = double2 chunks per lane per trip (one trip covers 2048 * MAXC2 doubles of the row).
-template <int MAXC2>
+// Workgroup 0 alone writes the control block; the pivot counter itself is committed by k_update
+// (st->iter is read by every head workgroup and must not change under them).
 __global__ __launch_bounds__(1024) void k_pivot_head(const double* __restrict__ T, int ld, int R,
                                                      int C, double* __restrict__ rowbuf,
                                                      double* __restrict__ colbuf,
                                                      const double* __restrict__ next_col,
                                                      const double* __restrict__ next_rhs,
                                                      int32_t* __restrict__ basis,
-                                                     int32_t* __restrict__ log, PivotState* st) {
+                                                     int32_t* __restrict__ log, PivotState* st,
+                                                     ZPart* __restrict__ zparts, int G) {
     __shared__ double lds_v[16];
     __shared__ int lds_i[16];
+    __shared__ double lds_p[2];  // [0] = T[r, e], [1] = T[0, e]
     const int tid = threadIdx.x;
     const int nt = blockDim.x;
+    const int g = blockIdx.x;
+    const bool lead = (g == 0);
 
-    if (st->status != kRunning) return;
-    const int e = st->next_e;
-    if (e < 0) {
-        if (tid == 0) st->status = LPR_OK_OPTIMAL;
-        return;
-    }
-
+    // Everything whose ADDRESS is known up front is requested before the first branch, so the
+    // control block, both partial banks, this lane's share of the dense vectors and its Z-row
+    // slice come back in ONE memory round trip (the caches were just flushed by the previous
+    // kernel's end: each dependent trip costs ~2 us here).
     const int ld2 = ld >> 1;
     const double2* __restrict__ zrow2 = reinterpret_cast<const double2*>(T);
     double2* __restrict__ out2 = reinterpret_cast<double2*>(rowbuf);
-
-    // The Z-row slice of the first trip does not depend on the ratio test: issue its loads now so
-    // that they overlap the dense-vector loads below.
-    double2 zv[MAXC2];
+    const int stride2 = G * nt;          // double2 chunks covered per trip by all workgroups
+    const int c2_first = g * nt + tid;   // this lane's chunk in the first trip
+    const int32_t status = st->status;
+    const int64_t it = st->iter;
+    const int64_t mx = st->max_iter;
+    Cand e0 = reduce_zparts(zparts, G);                   // bank 0
+    Cand e1 = reduce_zparts(zparts + kMaxHeadGroups, G);  // bank 1
+    double a0[8], b0[8];
 #pragma unroll
-    for (int u = 0; u < MAXC2; ++u) {
-        const int c2 = tid + u * nt;
-        zv[u] = (c2 < ld2) ? zrow2[c2] : make_double2(0.0, 0.0);
+    for (int u = 0; u < 8; ++u) {
+        const int i = tid + u * nt;
+        const bool in = i < R;
+        a0[u] = in ? next_col[i] : 0.0;
+        b0[u] = in ? next_rhs[i] : 0.0;
+    }
+    double2 zv = (c2_first < ld2) ? zrow2[c2_first] : make_double2(0.0, 0.0);
+
+    if (status != kRunning) return;
+    ZPart* __restrict__ bank_out = zparts + ((it + 1) & 1) * kMaxHeadGroups;
+    const int e = ((it & 1) ? e1 : e0).i;
+    if (e < 0) {
+        if (lead && tid == 0) st->status = LPR_OK_OPTIMAL;
+        return;
     }
 
     // ---- FindLeavingVariable on the dense vectors ----
-    __shared__ double lds_p[2];  // [0] = T[r, e], [1] = T[0, e]
     Cand c;
     c.v = DBL_MAX;
     c.i = -1;
     double a_of_best = 0.0;  // next_col[c.i], carried so that p needs no second global read
     for (int i0 = tid; i0 < R; i0 += 8 * nt) {
         double a[8], b[8];
+        if (i0 == tid) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = i0 + u * nt;
-            const bool in = i < R;
-            a[u] = in ? next_col[i] : 0.0;
-            b[u] = in ? next_rhs[i] : 0.0;
+            for (int u = 0; u < 8; ++u) {
+                a[u] = a0[u];
+                b[u] = b0[u];
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * nt;
+                const bool in = i < R;
+                a[u] = in ? next_col[i] : 0.0;
+                b[u] = in ? next_rhs[i] : 0.0;
+            }
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int i = i0 + u * nt;
             if (i < R) {
-                colbuf[i] = a[u];
+                if (lead) colbuf[i] = a[u];
                 if (i == 0) lds_p[1] = a[u];
                 if (i >= 1 && a[u] > 1e-9) {
                     const double ratio = b[u] / a[u];
@@ -348,79 +405,60 @@ __global__ __launch_bounds__(1024) void k_pivot_head(const double* __restrict__ 
     c = block_cand_min(c, lds_v, lds_i);
     const int r = c.i;
     if (r < 0) {
-        if (tid == 0) st->status = LPR_UNBOUNDED;
+        if (lead && tid == 0) st->status = LPR_UNBOUNDED;
         return;
     }
-    {
-        const int64_t it = st->iter;
-        const int64_t mx = st->max_iter;
-        if (mx > 0 && it >= mx) {
-            if (tid == 0) st->status = LPR_PIVOT_LIMIT;
-            return;
-        }
+    if (mx > 0 && it >= mx) {
+        if (lead && tid == 0) st->status = LPR_PIVOT_LIMIT;
+        return;
     }
     if (my_best == r) lds_p[0] = a_of_best;  // exactly one lane owns row r
     __syncthreads();
 
-    // ---- normalise row r, form the next Z row, pick the next entering column ----
+    // ---- normalise this workgroup's slice of row r, form the next Z row, partial arg-min ----
     const double p = lds_p[0];   // T[r, e]
     const double f0 = lds_p[1];  // T[0, e]
     const double2* __restrict__ prow2 = reinterpret_cast<const double2*>(T + (size_t)r * ld);
     Cand n;
     n.v = 0.0;
     n.i = -1;
-    for (int base = 0; base < ld2; base += nt * MAXC2) {  // one trip when ld <= 2048 * MAXC2
-        double2 pv[MAXC2];
-#pragma unroll
-        for (int u = 0; u < MAXC2; ++u) {  // all MAXC2 16-byte loads of the lane in flight at once
-            const int c2 = base + tid + u * nt;
-            pv[u] = (c2 < ld2) ? prow2[c2] : make_double2(0.0, 0.0);
+    for (int c2 = c2_first; c2 < ld2; c2 += stride2) {  // one trip unless ld > 2048 * G
+        const double2 pv = prow2[c2];
+        if (c2 != c2_first) zv = zrow2[c2];
+        const int j = 2 * c2;
+        double2 q;
+        q.x = (j < C) ? pv.x / p : 0.0;      // :199 true division
+        q.y = (j + 1 < C) ? pv.y / p : 0.0;
+        out2[c2] = q;
+        const double mx = f0 * q.x;          // :208 product rounded ...
+        const double my = f0 * q.y;
+        const double zx = zv.x - mx;         // ... then the difference
+        const double zy = zv.y - my;
+        if (j < C - 1 && zx < n.v) {
+            n.v = zx;
+            n.i = j;
         }
-        if (base > 0) {
-#pragma unroll
-            for (int u = 0; u < MAXC2; ++u) {
-                const int c2 = base + tid + u * nt;
-                zv[u] = (c2 < ld2) ? zrow2[c2] : make_double2(0.0, 0.0);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < MAXC2; ++u) {
-            const int c2 = base + tid + u * nt;
-            if (c2 < ld2) {
-                const int j = 2 * c2;
-                double2 q;
-                q.x = (j < C) ? pv[u].x / p : 0.0;      // :199 true division
-                q.y = (j + 1 < C) ? pv[u].y / p : 0.0;
-                out2[c2] = q;
-                const double mx = f0 * q.x;             // :208 product rounded ...
-                const double my = f0 * q.y;
-                const double zx = zv[u].x - mx;         // ... then the difference
-                const double zy = zv[u].y - my;
-                if (j < C - 1 && zx < n.v) {
-                    n.v = zx;
-                    n.i = j;
-                }
-                if (j + 1 < C - 1 && zy < n.v) {
-                    n.v = zy;
-                    n.i = j + 1;
-                }
-            }
+        if (j + 1 < C - 1 && zy < n.v) {
+            n.v = zy;
+            n.i = j + 1;
         }
     }
     n = block_cand_min(n, lds_v, lds_i);
 
     if (tid == 0) {
-        st->cur_r = r;
-        st->cur_e = e;
-        st->next_e = n.i;
-        basis[r - 1] = e;  // :142
-        const int64_t it = st->iter;
-        if (it < st->log_cap) {
-            log[2 * it] = r;
-            log[2 * it + 1] = e;
+        bank_out[g].v = n.v;
+        bank_out[g].i = n.i;
+        if (lead) {
+            st->cur_r = r;
+            st->cur_e = e;
+            basis[r - 1] = e;  // :142
+            if (it < st->log_cap) {
+                log[2 * it] = r;
+                log[2 * it + 1] = e;
+            }
+            st->iter_pending = it + 1;  // :138, committed to st->iter by k_update
+            st->sweep ^= 1;
         }
-        st->iter = it + 1;  // :138
-        st->sweep ^= 1;
     }
 }
 
@@ -436,21 +474,16 @@ template <int TR, int VPT, bool FULL>
 __device__ __forceinline__ void update_tile(double2* __restrict__ T2, int ld2, int R, int r,
                                             const double2* __restrict__ prow2,
                                             const double* __restrict__ colbuf, int i0,
-                                            int c2base, int ne, int rhs,
-                                            double* __restrict__ next_col,
+                                            int c2base, const ZPart* __restrict__ zbank, int G,
+                                            int rhs, double* __restrict__ next_col,
                                             double* __restrict__ next_rhs) {
     double2 pr[VPT];
     bool ok[VPT];
-    // lanes that own the next entering column / the RHS column copy their new values into the
-    // dense vectors read by the next k_pivot_head (ne < 0: nothing to dump)
-    int dump_e = -1, dump_rhs = -1;
 #pragma unroll
     for (int v = 0; v < VPT; ++v) {
         const int c2 = c2base + v * 256;
         ok[v] = FULL || c2 < ld2;
         pr[v] = ok[v] ? prow2[c2] : make_double2(0.0, 0.0);
-        if (ne >= 0 && c2 == (ne >> 1)) dump_e = v;
-        if (ne >= 0 && c2 == (rhs >> 1)) dump_rhs = v;
     }
     double2 x[TR][VPT];
 #pragma unroll
@@ -460,6 +493,19 @@ __device__ __forceinline__ void update_tile(double2* __restrict__ T2, int ld2, i
 #pragma unroll
             for (int v = 0; v < VPT; ++v)
                 if (ok[v]) x[k][v] = T2[(size_t)i * ld2 + c2base + v * 256];
+        }
+    }
+    // While the tile is in flight: which lanes own the next entering column / the RHS column?
+    // They copy their new values into the dense vectors read by the next k_pivot_head
+    // (zbank == nullptr: single-step pivot, nothing to dump).
+    int dump_e = -1, dump_rhs = -1, ne = -1;
+    if (zbank) {
+        ne = reduce_zparts(zbank, G).i;
+#pragma unroll
+        for (int v = 0; v < VPT; ++v) {
+            const int c2 = c2base + v * 256;
+            if (ne >= 0 && c2 == (ne >> 1)) dump_e = v;
+            if (ne >= 0 && c2 == (rhs >> 1)) dump_rhs = v;
         }
     }
 #pragma unroll
@@ -491,12 +537,15 @@ __global__ __launch_bounds__(256) void k_update(double* __restrict__ T, int ld, 
                                                 const double* __restrict__ rowbuf,
                                                 const double* __restrict__ colbuf,
                                                 double* __restrict__ next_col,
-                                                double* __restrict__ next_rhs,
-                                                const PivotState* __restrict__ st,
+                                                double* __restrict__ next_rhs, PivotState* st,
+                                                const ZPart* __restrict__ zparts, int G,
                                                 int check_status, int serpentine, int dump_next) {
     if (check_status && st->status != kRunning) return;
     const int r = st->cur_r;
-    const int ne = dump_next ? st->next_e : -1;
+    const int64_t itp = st->iter_pending;
+    if (dump_next && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+        st->iter = itp;  // commit the pivot counter (no k_update workgroup reads st->iter)
+    const ZPart* zbank = dump_next ? zparts + (itp & 1) * kMaxHeadGroups : nullptr;
     const int ld2 = ld >> 1;
     int ct = blockIdx.x, rt = blockIdx.y;
     if (serpentine && (st->sweep & 1)) {  // reverse the sweep on alternate pivots
@@ -510,10 +559,10 @@ __global__ __launch_bounds__(256) void k_update(double* __restrict__ T, int ld, 
     // interior tiles (the common case) run without any per-element guard
     const bool full = (i0 + TR <= R) && ((ct + 1) * (256 * VPT) <= ld2);
     if (full)
-        update_tile<TR, VPT, true>(T2, ld2, R, r, prow2, colbuf, i0, c2base, ne, C - 1, next_col,
-                                   next_rhs);
+        update_tile<TR, VPT, true>(T2, ld2, R, r, prow2, colbuf, i0, c2base, zbank, G, C - 1,
+                                   next_col, next_rhs);
     else
-        update_tile<TR, VPT, false>(T2, ld2, R, r, prow2, colbuf, i0, c2base, ne, C - 1,
+        update_tile<TR, VPT, false>(T2, ld2, R, r, prow2, colbuf, i0, c2base, zbank, G, C - 1,
                                     next_col, next_rhs);
 }
 
@@ -622,26 +671,25 @@ void launch_select(lpr_tableau* t, int mode, int e_in, int r_in, int32_t* out_i)
                        r_in, out_i);
 }
 
+// number of k_pivot_head workgroups: one per 1024 double2 of the row, capped
+int head_groups(const lpr_tableau* t) {
+    int g = (t->ld / 2 + 1023) / 1024;
+    if (g < 1) g = 1;
+    if (g > kMaxHeadGroups) g = kMaxHeadGroups;
+    return g;
+}
+
 void launch_bootstrap(lpr_tableau* t) {
     hipLaunchKernelGGL(k_bootstrap, dim3(1), dim3(1024), 0, t->eng->stream, t->T, t->ld, t->rows,
-                       t->cols, t->next_col, t->next_rhs, t->state);
+                       t->cols, t->next_col, t->next_rhs, t->state,
+                       reinterpret_cast<ZPart*>(t->zparts), head_groups(t));
 }
 
-template <int MAXC2>
-static void launch_pivot_head_t(lpr_tableau* t) {
-    hipLaunchKernelGGL((k_pivot_head<MAXC2>), dim3(1), dim3(1024), 0, t->eng->stream, t->T, t->ld,
-                       t->rows, t->cols, t->rowbuf, t->colbuf, t->next_col, t->next_rhs, t->basis,
-                       t->log, t->state);
-}
-
-// Pick the smallest instantiation that covers the row in one trip (MAXC2 = 8 keeps the 1024-thread
-// workgroup under its 128-VGPR budget; wider rows take several trips).
 void launch_pivot_head(lpr_tableau* t) {
-    const int need = (t->ld / 2 + 1023) / 1024;
-    if (need <= 1) launch_pivot_head_t<1>(t);
-    else if (need <= 2) launch_pivot_head_t<2>(t);
-    else if (need <= 4) launch_pivot_head_t<4>(t);
-    else launch_pivot_head_t<8>(t);
+    const int G = head_groups(t);
+    hipLaunchKernelGGL(k_pivot_head, dim3(G), dim3(1024), 0, t->eng->stream, t->T, t->ld, t->rows,
+                       t->cols, t->rowbuf, t->colbuf, t->next_col, t->next_rhs, t->basis, t->log,
+                       t->state, reinterpret_cast<ZPart*>(t->zparts), G);
 }
 
 template <int TR, int VPT>
@@ -650,7 +698,8 @@ static void launch_update_t(lpr_tableau* t, int check_status, int serpentine, in
     dim3 grid((ld2 + 256 * VPT - 1) / (256 * VPT), (t->rows + TR - 1) / TR);
     hipLaunchKernelGGL((k_update<TR, VPT>), grid, dim3(256), 0, t->eng->stream, t->T, t->ld,
                        t->rows, t->cols, t->rowbuf, t->colbuf, t->next_col, t->next_rhs, t->state,
-                       check_status, serpentine, dump_next);
+                       reinterpret_cast<const ZPart*>(t->zparts), head_groups(t), check_status,
+                       serpentine, dump_next);
 }
 
 // variant: low byte selects the tile shape, bit 8 turns the serpentine sweep on.

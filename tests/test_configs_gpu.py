@@ -1,0 +1,110 @@
+"""GPU parity tests at the sizes of BASELINE.json's remaining configs:
+  configs[3]  Branch & Bound with ~256 live LP sub-problems (level-synchronous, batched children)
+  configs[4]  degenerate / tie-saturated LP, m = n = 2048 (anti-cycling, wavefront arg-min stress)
+(configs[0] sample LP, configs[1] m=512 and configs[2] m=4096 live in test_primal_gpu.py /
+test_revised_gpu.py.)"""
+import hashlib
+import struct
+
+import numpy as np
+import pytest
+
+import bb_cases
+from oracle_evaluator import OracleEvaluator
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(x):
+    return struct.pack(">d", float(x)).hex()
+
+
+def degenerate_tableau(m: int, n: int, seed: int):
+    """Tie-saturated LP: small-integer coefficients, a third of the right-hand sides zero (every
+    early ratio test is a many-way tie at ratio 0), objective coefficients drawn from 4 values
+    (many-way ties in the entering scan).  All values stay far inside 2^+-50."""
+    rng = np.random.RandomState(seed)
+    A = rng.randint(0, 5, size=(m, n)).astype(np.float64)
+    b = rng.randint(0, 3, size=m).astype(np.float64) * rng.randint(1, 50, size=m)
+    c = rng.randint(1, 5, size=n).astype(np.float64)
+    T = np.zeros((m + 1, n + m + 1))
+    T[0, :n] = -c
+    T[1:, :n] = A
+    T[1:, n:n + m] = np.eye(m)
+    T[1:, -1] = b
+    basis = (n + np.arange(m)).astype(np.int32)
+    return T, basis
+
+
+def test_config4_degenerate_m2048_fixed_pivot_budget(engine, oracle):
+    from lpr_381_group_v22_amd import Tableau
+    m = n = 2048
+    K = 160
+    T, basis = degenerate_tableau(m, n, 4)
+    tab = Tableau.from_array(engine, T, basis)
+    st, piv, log = oracle.primal_solve(T, basis, K)
+    res = tab.solve(max_pivots=K)
+    assert res.status == st and res.pivots == piv
+    assert tab.pivot_log().tolist() == log.tolist(), "pivot indices differ from the oracle"
+    assert tab.basis().tolist() == basis.tolist()
+    zero_ratio = int((T[1:, -1] == 0).sum())
+    assert zero_ratio > 200, "fixture must stay degenerate"
+    got = tab.read()
+    assert hashlib.sha256(got.tobytes()).hexdigest() == hashlib.sha256(T.tobytes()).hexdigest()
+    tab.destroy()
+
+
+def test_config4_klee_minty_bounded_full_path(engine, oracle):
+    """Klee-Minty-style cube (growth base 2, d = 14): Dantzig's rule walks an exponentially long
+    path; every pivot index must match the oracle."""
+    import lp_cases
+    from lpr_381_group_v22_amd import Constraint, PrimalSimplexSolver
+    obj, cons, is_max = lp_cases.klee_minty_bounded(14)
+    o, A, ncoef, rel, rhs = lp_cases.flatten(obj, cons)
+    T, basis = oracle.primal_build(o, A, rel, rhs, is_max, ncoef)
+    st, piv, log = oracle.primal_solve(T, basis, 100000, log_cap=1 << 17)
+    s = PrimalSimplexSolver(obj, [Constraint(list(c.Coefficients), c.Relation, c.RHS)
+                                  for c in cons], is_max, engine=engine, snapshots="none")
+    s.Solve(max_pivots=100000)
+    assert s.Status == st == 0
+    assert s.PivotLog.tolist() == log.tolist()
+    assert s.GetFinalTableau().tobytes() == T.tobytes()
+    assert bits(s.FinalZ) == bits(T[0, -1])
+
+
+def test_config3_bb_hundreds_of_live_subproblems(engine, oracle):
+    """~256 live LP sub-problems: the frontier of a 9-level tree evaluated level by level, all
+    children of a level in ONE batched expand on the GPU; same driver with the oracle-backed
+    evaluator as the checker."""
+    from lpr_381_group_v22_amd import BranchBoundTree, solve_level_synchronous
+    obj, cons = bb_cases.random_binary_program(40, 5, 77)
+    st, T, n = bb_cases.primal_final_tableau(oracle, obj, cons)
+    levels = 9
+    tree = BranchBoundTree.from_array(engine, T, n, max_depth=levels + 2)
+
+    class Counting:
+        def __init__(self, inner):
+            self.inner = inner
+            self.max_batch = 0
+
+        def node_info(self, ids):
+            return self.inner.node_info(ids)
+
+        def expand(self, p, v, b, k):
+            self.max_batch = max(self.max_batch, len(p))
+            return self.inner.expand(p, v, b, k)
+
+        def release(self, ids):
+            return self.inner.release(ids)
+
+    gpu_ev = Counting(tree)
+    got = solve_level_synchronous(gpu_ev, n, max_levels=levels)
+    tree.destroy()
+    ref = solve_level_synchronous(OracleEvaluator(oracle, T, n), n, max_levels=levels)
+    assert gpu_ev.max_batch >= 128, f"largest batch was only {gpu_ev.max_batch} children"
+    assert got["processed"] == ref["processed"] and got["pivots"] == ref["pivots"]
+    assert got["levels"] == ref["levels"]
+    assert got["found"] == ref["found"] and bits(got["z"]) == bits(ref["z"])
+    if ref["found"]:
+        assert [bits(v) for v in got["x"]] == [bits(v) for v in ref["x"]]
+        assert tuple(got["path"]) == tuple(ref["path"])
