@@ -419,19 +419,42 @@ constexpr int LDA_S = GK + 1;   // Bz tile stored [row][k], padded: the A-operan
 constexpr int LDB_S = GN + 16;  // A tile stored [k][col]; +16 doubles = 32 banks: k and k+1 rows
                                 // of one ds_read_b64 land on disjoint bank halves
 
-__global__ __launch_bounds__(256) void k_rev_gemm(const double* __restrict__ Binv, int ldb,
-                                                  const double* __restrict__ A, int lda,
-                                                  double* __restrict__ Cout, int ldc, int m,
-                                                  int n) {
-    __shared__ double sA[2][GM * LDA_S];
-    __shared__ double sB[2][GK * LDB_S];
+// XCD-aware tile order (8 XCDs, each with its own L2): workgroups are dealt round-robin over the
+// XCDs by the dispatcher, so the linear id is first split into (xcd, slot); each XCD then walks a
+// contiguous share of the tile grid in "grouped" order (GROUP_M row tiles per column sweep) so
+// that the B^-1 row panels and A column panels it touches stay resident in ITS 4 MiB L2.
+__device__ __forceinline__ void gemm_tile_of_block(int& tm, int& tn, int gm, int gn) {
+    const int nblk = gm * gn;
+    int bid = blockIdx.x;
+    constexpr int NXCD = 8;
+    if (nblk % NXCD == 0) {
+        const int per = nblk / NXCD;
+        bid = (bid % NXCD) * per + bid / NXCD;
+    }
+    constexpr int GROUP_M = 4;
+    const int width = GROUP_M * gn;
+    const int group = bid / width;
+    const int first_m = group * GROUP_M;
+    const int gsz = min(gm - first_m, GROUP_M);
+    tm = first_m + (bid % width) % gsz;
+    tn = (bid % width) / gsz;
+}
+
+__global__ __launch_bounds__(256, 2) void k_rev_gemm(const double* __restrict__ Binv, int ldb,
+                                                     const double* __restrict__ A, int lda,
+                                                     double* __restrict__ Cout, int ldc, int m,
+                                                     int n, int gm, int gn) {
+    __shared__ __attribute__((aligned(16))) double sA[2][GM * LDA_S];
+    __shared__ __attribute__((aligned(16))) double sB[2][GK * LDB_S];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = (wave >> 1) * 64;  // wave tile origin inside the block tile
     const int wn = (wave & 1) * 64;
-    const int bm = blockIdx.y * GM;
-    const int bn = blockIdx.x * GN;
+    int tm, tn;
+    gemm_tile_of_block(tm, tn, gm, gn);
+    const int bm = tm * GM;
+    const int bn = tn * GN;
 
     double4_t acc[4][4];
 #pragma unroll
@@ -439,32 +462,59 @@ __global__ __launch_bounds__(256) void k_rev_gemm(const double* __restrict__ Bin
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
 
-    // global -> LDS staging maps: Bz tile 128 x 16 (2048 doubles, 8 per thread), A tile 16 x 128
-    auto stage = [&](int buf, int k0) {
+    // Staging maps (16-byte global loads; rows are 128-byte aligned, ld % 16 == 0):
+    //   B^-1 tile 128 x 16: 1024 double2, 4 per lane: row = idx >> 3, k pair = idx & 7
+    //   A    tile  16 x 128: 1024 double2, 4 per lane: k   = idx >> 6, col pair = idx & 63
+    double2 ra[4], rb[4];
+    auto load_tile = [&](int k0) {  // global -> registers; no wait here
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int idx = tid + q * 256;  // 0..2047
-            const int r = idx >> 4, kk = idx & 15;
+        for (int q = 0; q < 4; ++q) {
+            const int idx = tid + q * 256;
+            const int r = idx >> 3, kk = (idx & 7) * 2;
             const int gi = bm + r, gk = k0 + kk;
-            double v = (gi < m && gk < m) ? Binv[(size_t)gi * ldb + gk] : 0.0;
-            if (fabs(v) < kEps) v = 0.0;  // :436 zero-skip
-            sA[buf][r * LDA_S + kk] = v;
+            ra[q] = (gi < m && gk < ldb)
+                        ? *reinterpret_cast<const double2*>(Binv + (size_t)gi * ldb + gk)
+                        : make_double2(0.0, 0.0);
         }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < 4; ++q) {
             const int idx = tid + q * 256;
-            const int kk = idx >> 7, cidx = idx & 127;
-            const int gk = k0 + kk, gj = bn + cidx;
-            sB[buf][kk * LDB_S + cidx] = (gk < m && gj < n) ? A[(size_t)gk * lda + gj] : 0.0;
+            const int kk = idx >> 6, cc = (idx & 63) * 2;
+            const int gk = k0 + kk, gj = bn + cc;
+            rb[q] = (gk < m && gj < lda)
+                        ? *reinterpret_cast<const double2*>(A + (size_t)gk * lda + gj)
+                        : make_double2(0.0, 0.0);
+        }
+    };
+    auto store_tile = [&](int buf, int k0) {  // registers -> LDS
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = tid + q * 256;
+            const int r = idx >> 3, kk = (idx & 7) * 2;
+            double vx = ra[q].x, vy = ra[q].y;
+            if (k0 + kk >= m || fabs(vx) < kEps) vx = 0.0;      // :436 zero-skip; k beyond m is 0
+            if (k0 + kk + 1 >= m || fabs(vy) < kEps) vy = 0.0;
+            sA[buf][r * LDA_S + kk] = vx;
+            sA[buf][r * LDA_S + kk + 1] = vy;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = tid + q * 256;
+            const int kk = idx >> 6, cc = (idx & 63) * 2;
+            double vx = rb[q].x, vy = rb[q].y;
+            if (bn + cc >= n) vx = 0.0;      // padding columns of A are 0 anyway
+            if (bn + cc + 1 >= n) vy = 0.0;
+            *reinterpret_cast<double2*>(&sB[buf][kk * LDB_S + cc]) = make_double2(vx, vy);
         }
     };
 
     const int nk = (m + GK - 1) / GK;
-    stage(0, 0);
+    load_tile(0);
+    store_tile(0, 0);
     __syncthreads();
     for (int t = 0; t < nk; ++t) {
         const int buf = t & 1;
-        if (t + 1 < nk) stage(buf ^ 1, (t + 1) * GK);
+        if (t + 1 < nk) load_tile((t + 1) * GK);  // in flight under the 64 MFMAs below
 #pragma unroll
         for (int ks = 0; ks < GK; ks += 4) {
             double af[4], bf[4];
@@ -481,6 +531,7 @@ __global__ __launch_bounds__(256) void k_rev_gemm(const double* __restrict__ Bin
                     acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0,
                                                                      0, 0);
         }
+        if (t + 1 < nk) store_tile(buf ^ 1, (t + 1) * GK);
         __syncthreads();
     }
 
@@ -543,9 +594,9 @@ void rev_launch_synthetic(lpr_revised* s, uint64_t seed) {
 }
 
 void rev_launch_gemm(lpr_revised* s, double* Cout, int ldc) {
-    dim3 grid((s->n + GN - 1) / GN, (s->m + GM - 1) / GM);
-    hipLaunchKernelGGL(k_rev_gemm, grid, dim3(256), 0, s->eng->stream, s->Binv, s->ldb, s->A,
-                       s->lda, Cout, ldc, s->m, s->n);
+    const int gn = (s->n + GN - 1) / GN, gm = (s->m + GM - 1) / GM;
+    hipLaunchKernelGGL(k_rev_gemm, dim3(gm * gn), dim3(256), 0, s->eng->stream, s->Binv, s->ldb,
+                       s->A, s->lda, Cout, ldc, s->m, s->n, gm, gn);
 }
 
 }  // namespace lpr

@@ -50,13 +50,15 @@ int main() {
     hipGetDeviceProperties(&p, 0);
     const int cus = p.multiProcessorCount;
     double best = 0;
-    for (int wpc : {1, 2}) {  // workgroups per CU (4 or 8 waves per CU)
+    for (int wpc : {1, 2, 4, 8}) {  // workgroups per CU (4 .. 32 waves per CU)
         const double t4 = run<4>(cus * wpc, 20000);
         const double t8 = run<8>(cus * wpc, 10000);
-        printf("{\"cus\": %d, \"wg_per_cu\": %d, \"tflops_4acc\": %.2f, \"tflops_8acc\": %.2f}\n",
-               cus, wpc, t4, t8);
+        const double t16 = run<16>(cus * wpc, 5000);
+        printf("{\"cus\": %d, \"wg_per_cu\": %d, \"tflops_4acc\": %.2f, \"tflops_8acc\": %.2f, "
+               "\"tflops_16acc\": %.2f}\n", cus, wpc, t4, t8, t16);
         if (t4 > best) best = t4;
         if (t8 > best) best = t8;
+        if (t16 > best) best = t16;
     }
     printf("{\"mfma_f64_16x16x4_peak_tflops\": %.2f}\n", best);
     return 0;
