@@ -25,81 +25,201 @@ namespace lpr {
 constexpr double kEps = 1e-9;  // RevisedPrimalSimplexSolver.cs:12
 
 // ------------------------------------------------------------------------------------------
-// out[i] = sum_{j asc} M[i, j] * v[j], one lane per row, s starts at +0.0.
-// Rows are 128-byte aligned (ld % 16 == 0) so a lane reads its row 16 bytes at a time; 8 loads
-// are in flight per lane.  `skip_if_slack`: the u = B^-1 a_e launch is a no-op when the entering
-// variable is a slack (then u is a column of B^-1, written by k_rev_gather).
-__global__ __launch_bounds__(64) void k_rev_rowsum(const double* __restrict__ M, int ld, int m,
-                                                   const double* __restrict__ v,
-                                                   double* __restrict__ out,
-                                                   const RevState* __restrict__ st,
-                                                   int skip_if_slack, int n) {
+// out[i] = sum_{j asc} M[i, j] * v[j], s starts at +0.0  (MultiplyMatrixVector :398-410).
+// The sum of one row is a serial chain of m rounded multiply-adds -- that order is what the C#
+// computes and what the pivot decisions depend on -- so its floor is the fp64 add latency times m.
+// Everything else is made parallel: a 256-thread workgroup owns RB = 16 rows; ALL its lanes stream
+// the rows in KC-column chunks with 16-byte coalesced loads into a double-buffered LDS tile while
+// 16 lanes (one per row) walk the previous chunk out of LDS in order.  m/16 workgroups keep every
+// CU busy pulling its own 16 rows (a CU can only pull ~50 GB/s; one lane per row left 3/4 of the
+// chip idle).  `skip_if_slack`: the u = B^-1 a_e launch is a no-op when the entering variable is
+// a slack (then u is a column of B^-1, written by k_rev_gather).
+constexpr int kGRP = 16;   // operands fetched from LDS one group ahead of the add chain
+constexpr int kRB = 16;    // rows per workgroup
+constexpr int kKC = 128;   // columns per chunk
+
+__global__ __launch_bounds__(256) void k_rev_rowsum(const double* __restrict__ M, int ld, int m,
+                                                    const double* __restrict__ v,
+                                                    double* __restrict__ out,
+                                                    const RevState* __restrict__ st,
+                                                    int skip_if_slack, int n) {
+    // +2 doubles per row: rows stay 16-byte aligned and the 16 consumer lanes hit disjoint banks
+    // (kGRP more so that the one-group-ahead prefetch of the last group stays inside the array)
+    __shared__ __attribute__((aligned(16))) double sM[2][kRB][kKC + kGRP + 2];
+    __shared__ __attribute__((aligned(16))) double sv[2][kKC + kGRP];
     if (st->status != kRunning) return;
     if (skip_if_slack && st->entering >= n) return;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
-    const double2* __restrict__ row = reinterpret_cast<const double2*>(M + (size_t)i * ld);
-    const int m2 = m >> 1;
-    double s = 0.0;
-    int k2 = 0;
-    for (; k2 + 8 <= m2; k2 += 8) {
-        double2 a[8];
+    const int tid = threadIdx.x;
+    const int row0 = blockIdx.x * kRB;
+    const int nchunk = (m + kKC - 1) / kKC;
+    // staging map: kRB * kKC / 2 = 1024 double2 per chunk, 4 per lane; row = idx / 64
+    double2 rm[4];
+    double rv = 0.0;
+    auto load_chunk = [&](int k0) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) a[u] = row[k2 + u];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const double p0 = a[u].x * v[2 * (k2 + u)];
-            s = s + p0;
-            const double p1 = a[u].y * v[2 * (k2 + u) + 1];
-            s = s + p1;
+        for (int q = 0; q < 4; ++q) {
+            const int idx = tid + q * 256;
+            const int r = idx >> 6, k = (idx & 63) * 2;
+            const int gi = row0 + r, gk = k0 + k;
+            rm[q] = (gi < m && gk < ld)
+                        ? *reinterpret_cast<const double2*>(M + (size_t)gi * ld + gk)
+                        : make_double2(0.0, 0.0);
         }
+        if (tid < kKC) rv = (k0 + tid < m) ? v[k0 + tid] : 0.0;
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = tid + q * 256;
+            const int r = idx >> 6, k = (idx & 63) * 2;
+            sM[buf][r][k] = rm[q].x;
+            sM[buf][r][k + 1] = rm[q].y;
+        }
+        if (tid < kKC) sv[buf][tid] = rv;
+    };
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    double s = 0.0;
+    for (int c = 0; c < nchunk; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunk) load_chunk((c + 1) * kKC);  // in flight under the serial walk below
+        if (tid < kRB) {
+            // the serial walk: the products are independent, only the adds form the chain
+            const int kmax = min(kKC, m - c * kKC);
+            const double* __restrict__ row = sM[buf][tid];
+            const double* __restrict__ vv = sv[buf];
+            if (kmax == kKC) {
+                double a[kGRP], b[kGRP];
+#pragma unroll
+                for (int u = 0; u < kGRP; ++u) {
+                    a[u] = row[u];
+                    b[u] = vv[u];
+                }
+#pragma unroll
+                for (int k0 = 0; k0 < kKC; k0 += kGRP) {
+                    double na[kGRP], nb[kGRP];
+#pragma unroll
+                    for (int u = 0; u < kGRP; ++u) {  // next group: in flight under the adds below
+                        na[u] = row[k0 + kGRP + u];
+                        nb[u] = vv[k0 + kGRP + u];
+                    }
+#pragma unroll
+                    for (int u = 0; u < kGRP; ++u) {
+                        const double p = a[u] * b[u];  // product rounded ...
+                        s = s + p;                     // ... then added (:406)
+                    }
+#pragma unroll
+                    for (int u = 0; u < kGRP; ++u) {
+                        a[u] = na[u];
+                        b[u] = nb[u];
+                    }
+                }
+            } else {
+                for (int k = 0; k < kmax; ++k) {
+                    const double p = row[k] * vv[k];
+                    s = s + p;
+                }
+            }
+        }
+        if (c + 1 < nchunk) store_chunk(buf ^ 1);
+        __syncthreads();
     }
-    for (; k2 < m2; ++k2) {
-        const double2 a = row[k2];
-        const double p0 = a.x * v[2 * k2];
-        s = s + p0;
-        const double p1 = a.y * v[2 * k2 + 1];
-        s = s + p1;
-    }
-    if (m & 1) {
-        const double p0 = M[(size_t)i * ld + (m - 1)] * v[m - 1];
-        s = s + p0;
-    }
-    out[i] = s;
+    if (tid < kRB && row0 + tid < m) out[row0 + tid] = s;
 }
 
 // ------------------------------------------------------------------------------------------
-// s_j = sum_{i asc} v[i] * M[i, j], one lane per column (coalesced across lanes), s starts +0.0.
+// s_j = sum_{i asc} v[i] * M[i, j], s starts +0.0  (MultiplyVectorMatrix :412-424, and Dot(y,
+// GetColumn(A, j)) :98 -- y[i] * col[i] is the same product, IEEE multiplication commutes).
 //   mode 0: out[j] = s_j                (y = c_B B^-1)
-//   mode 1: out[j] = c[j] - s_j         (rc_j = c_j - Dot(y, GetColumn(A, j)), :98)
-// Dot(y, col) multiplies y[i] * col[i] -- the same operand order as v[i] * M[i, j]; IEEE
-// multiplication is commutative, so MultiplyVectorMatrix and Dot share this kernel.
-__global__ __launch_bounds__(64) void k_rev_colsum(const double* __restrict__ M, int ld, int rows,
-                                                   int cols, const double* __restrict__ v,
-                                                   const double* __restrict__ c,
-                                                   double* __restrict__ out, int mode,
-                                                   const RevState* __restrict__ st) {
+//   mode 1: out[j] = c[j] - s_j         (rc_j = c_j - Dot(y, A_j))
+// Same producer/consumer shape as k_rev_rowsum, transposed: a workgroup owns CB = 16 columns (one
+// 128-byte line per row), all 256 lanes stream RC-row chunks into LDS, 16 lanes (one per column)
+// walk the chunk in row order.  cols/16 workgroups (512 for A at n = 8192).
+constexpr int kCB = 16;    // columns per workgroup
+constexpr int kRC = 128;   // rows per chunk
+
+__global__ __launch_bounds__(256) void k_rev_colsum(const double* __restrict__ M, int ld, int rows,
+                                                    int cols, const double* __restrict__ v,
+                                                    const double* __restrict__ c,
+                                                    double* __restrict__ out, int mode,
+                                                    const RevState* __restrict__ st) {
+    __shared__ __attribute__((aligned(16))) double sM[2][kRC + kGRP][kCB];
+    __shared__ __attribute__((aligned(16))) double sv[2][kRC + kGRP];
     if (st->status != kRunning) return;
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= cols) return;
-    const double* __restrict__ col = M + j;
-    double s = 0.0;
-    int i = 0;
-    for (; i + 16 <= rows; i += 16) {
-        double a[16];
+    const int tid = threadIdx.x;
+    const int j0 = blockIdx.x * kCB;
+    const int nchunk = (rows + kRC - 1) / kRC;
+    // staging map: kRC * kCB / 2 = 1024 double2 per chunk, 4 per lane; row = idx / 8
+    double2 rm[4];
+    double rv = 0.0;
+    auto load_chunk = [&](int i0) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) a[u] = col[(size_t)(i + u) * ld];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const double p = v[i + u] * a[u];
-            s = s + p;
+        for (int q = 0; q < 4; ++q) {
+            const int idx = tid + q * 256;
+            const int r = idx >> 3, cc = (idx & 7) * 2;
+            const int gi = i0 + r;
+            rm[q] = (gi < rows)
+                        ? *reinterpret_cast<const double2*>(M + (size_t)gi * ld + j0 + cc)
+                        : make_double2(0.0, 0.0);
         }
+        if (tid < kRC) rv = (i0 + tid < rows) ? v[i0 + tid] : 0.0;
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = tid + q * 256;
+            const int r = idx >> 3, cc = (idx & 7) * 2;
+            *reinterpret_cast<double2*>(&sM[buf][r][cc]) = rm[q];
+        }
+        if (tid < kRC) sv[buf][tid] = rv;
+    };
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    double s = 0.0;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int buf = ch & 1;
+        if (ch + 1 < nchunk) load_chunk((ch + 1) * kRC);
+        if (tid < kCB) {
+            const int imax = min(kRC, rows - ch * kRC);
+            if (imax == kRC) {
+                double a[kGRP], b[kGRP];
+#pragma unroll
+                for (int u = 0; u < kGRP; ++u) {
+                    a[u] = sM[buf][u][tid];
+                    b[u] = sv[buf][u];
+                }
+#pragma unroll
+                for (int i0 = 0; i0 < kRC; i0 += kGRP) {
+                    double na[kGRP], nb[kGRP];
+#pragma unroll
+                    for (int u = 0; u < kGRP; ++u) {
+                        na[u] = sM[buf][i0 + kGRP + u][tid];
+                        nb[u] = sv[buf][i0 + kGRP + u];
+                    }
+#pragma unroll
+                    for (int u = 0; u < kGRP; ++u) {
+                        const double p = b[u] * a[u];  // v[i] * M[i, j] rounded ...
+                        s = s + p;                     // ... then added (:420)
+                    }
+#pragma unroll
+                    for (int u = 0; u < kGRP; ++u) {
+                        a[u] = na[u];
+                        b[u] = nb[u];
+                    }
+                }
+            } else {
+                for (int i = 0; i < imax; ++i) {
+                    const double p = sv[buf][i] * sM[buf][i][tid];
+                    s = s + p;
+                }
+            }
+        }
+        if (ch + 1 < nchunk) store_chunk(buf ^ 1);
+        __syncthreads();
     }
-    for (; i < rows; ++i) {
-        const double p = v[i] * col[(size_t)i * ld];
-        s = s + p;
-    }
-    out[j] = mode ? (c[j] - s) : s;
+    if (tid < kCB && j0 + tid < cols) out[j0 + tid] = mode ? (c[j0 + tid] - s) : s;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -148,16 +268,39 @@ __global__ __launch_bounds__(1024) void k_rev_enter(const double* __restrict__ r
     }
 
     const int N = n + m;
-    int cur = -1;          // enteringIdx
+    // Candidate values are read ONCE into registers (first kCacheE * 1024 indices; anything beyond
+    // is re-read from memory): -inf marks "not a candidate" (basic, or rc <= EPS).
+    constexpr int kCacheE = 16;
+    double val[kCacheE];
+#pragma unroll
+    for (int u = 0; u < kCacheE; ++u) {
+        const int k = tid + u * nt;
+        double rc = -INFINITY;
+        if (k < N && !is_basic[k]) {
+            rc = (k < n) ? rcx[k] : -y[k - n];  // rcS_k = -y_k (:100-102)
+            if (!(rc > kEps)) rc = -INFINITY;
+        }
+        val[u] = rc;
+    }
+    int cur = -1;             // enteringIdx
     double best = -INFINITY;  // bestPosRC
     for (;;) {
         int first = INT_MAX;
-        for (int k = tid; k < N; k += nt) {
-            if (k <= cur || is_basic[k]) continue;
-            const double rc = (k < n) ? rcx[k] : -y[k - n];  // rcS_k = -y_k (:100-102)
-            if (rc > kEps && (cur == -1 || rc > best + kEps)) {
-                first = k;
-                break;  // this lane's indices ascend: its first hit is its smallest
+#pragma unroll
+        for (int u = 0; u < kCacheE; ++u) {
+            const int k = tid + u * nt;
+            if (first == INT_MAX && k > cur && val[u] > -INFINITY &&
+                (cur == -1 || val[u] > best + kEps))
+                first = k;  // this lane's indices ascend: its first hit is its smallest
+        }
+        if (first == INT_MAX) {
+            for (int k = tid + kCacheE * nt; k < N; k += nt) {
+                if (k <= cur || is_basic[k]) continue;
+                const double rc = (k < n) ? rcx[k] : -y[k - n];
+                if (rc > kEps && (cur == -1 || rc > best + kEps)) {
+                    first = k;
+                    break;
+                }
             }
         }
         first = block_min_int(first, lds);
@@ -213,21 +356,49 @@ __global__ __launch_bounds__(1024) void k_rev_ratio(const double* __restrict__ u
     const int nt = blockDim.x;
     const int e = st->entering;
 
+    // Ratios and basic-variable indices of this lane's rows are computed ONCE into registers
+    // (first kCacheR * 1024 rows; rows beyond are re-read): NaN marks "u_i <= EPS" (:161,:172-175).
+    constexpr int kCacheR = 8;
+    double rat[kCacheR];
+    int bvi[kCacheR];
+#pragma unroll
+    for (int q = 0; q < kCacheR; ++q) {
+        const int i = tid + q * nt;
+        rat[q] = NAN;
+        bvi[q] = 0;
+        if (i < m) {
+            const double ui = u[i];
+            if (ui > kEps) rat[q] = xB[i] / ui;
+            bvi[q] = basic[i];
+        }
+    }
+    const bool cached_all = m <= kCacheR * nt;
     int row = -1;           // leavingRow
     double best = DBL_MAX;  // bestRatio
     int cur = -1;           // last index examined by the replayed loop
     for (;;) {
         const int brow = (row >= 0) ? basic[row] : 0;
         int first = INT_MAX;
-        for (int i = tid; i < m; i += nt) {
-            if (i <= cur) continue;
-            const double ui = u[i];
-            if (!(ui > kEps)) continue;
-            const double ratio = xB[i] / ui;
-            if (ratio < best - kEps ||
-                (fabs(ratio - best) <= kEps && (row == -1 || basic[i] < brow))) {
+#pragma unroll
+        for (int q = 0; q < kCacheR; ++q) {
+            const int i = tid + q * nt;
+            const double ratio = rat[q];  // NaN fails both tests below, as the C# skips the row
+            if (first == INT_MAX && i < m && i > cur &&
+                (ratio < best - kEps ||
+                 (fabs(ratio - best) <= kEps && (row == -1 || bvi[q] < brow))))
                 first = i;
-                break;
+        }
+        if (first == INT_MAX && !cached_all) {
+            for (int i = tid + kCacheR * nt; i < m; i += nt) {
+                if (i <= cur) continue;
+                const double ui = u[i];
+                if (!(ui > kEps)) continue;
+                const double ratio = xB[i] / ui;
+                if (ratio < best - kEps ||
+                    (fabs(ratio - best) <= kEps && (row == -1 || basic[i] < brow))) {
+                    first = i;
+                    break;
+                }
             }
         }
         first = block_min_int(first, lds);
@@ -554,21 +725,21 @@ void rev_launch_iteration(lpr_revised* s) {
     hipStream_t st = s->eng->stream;
     const int m = s->m, n = s->n;
     // x_B = B^-1 b (:89)
-    hipLaunchKernelGGL(k_rev_rowsum, dim3((m + 63) / 64), dim3(64), 0, st, s->Binv, s->ldb, m,
-                       s->b, s->xB, s->state, 0, n);
+    hipLaunchKernelGGL(k_rev_rowsum, dim3((m + kRB - 1) / kRB), dim3(256), 0, st, s->Binv, s->ldb,
+                       m, s->b, s->xB, s->state, 0, n);
     // y = c_B B^-1 (:93)
-    hipLaunchKernelGGL(k_rev_colsum, dim3((m + 63) / 64), dim3(64), 0, st, s->Binv, s->ldb, m, m,
-                       s->cB, (const double*)nullptr, s->y, 0, s->state);
+    hipLaunchKernelGGL(k_rev_colsum, dim3((m + kCB - 1) / kCB), dim3(256), 0, st, s->Binv, s->ldb,
+                       m, m, s->cB, (const double*)nullptr, s->y, 0, s->state);
     // rc_j = c_j - y.A_j (:96-98)
-    hipLaunchKernelGGL(k_rev_colsum, dim3((n + 63) / 64), dim3(64), 0, st, s->A, s->lda, m, n,
-                       s->y, s->c, s->rcx, 1, s->state);
+    hipLaunchKernelGGL(k_rev_colsum, dim3((n + kCB - 1) / kCB), dim3(256), 0, st, s->A, s->lda, m,
+                       n, s->y, s->c, s->rcx, 1, s->state);
     hipLaunchKernelGGL(k_rev_enter, dim3(1), dim3(1024), 0, st, s->rcx, s->y, s->xB, s->is_basic,
                        n, m, s->state);
     hipLaunchKernelGGL(k_rev_gather, dim3((m + 255) / 256), dim3(256), 0, st, s->A, s->lda,
                        s->Binv, s->ldb, n, m, s->acol, s->u, s->state);
     // u = B^-1 a_e (:150) unless the entering variable is a slack
-    hipLaunchKernelGGL(k_rev_rowsum, dim3((m + 63) / 64), dim3(64), 0, st, s->Binv, s->ldb, m,
-                       s->acol, s->u, s->state, 1, n);
+    hipLaunchKernelGGL(k_rev_rowsum, dim3((m + kRB - 1) / kRB), dim3(256), 0, st, s->Binv, s->ldb,
+                       m, s->acol, s->u, s->state, 1, n);
     hipLaunchKernelGGL(k_rev_ratio, dim3(1), dim3(1024), 0, st, s->u, s->xB, s->basic,
                        s->is_basic, s->cB, s->c, s->Binv, s->ldb, s->browbuf, s->fac, s->log, n, m,
                        s->state);
