@@ -1,17 +1,21 @@
 #!/usr/bin/env python3
-"""Headline benchmark: full-tableau primal-simplex pivots/s on the m=4096, n=8192 dense random LP
-(4097 x 12289 fp64 tableau, 402.8 MB) and the HBM-roofline fraction of the rank-1 update kernel.
+"""Benchmarks of the MI355X simplex pivot engine.  Rank 0 prints ONE JSON line.
 
-    python bench.py --gpus 1 --steps 512 --warmup 64
+    python bench.py --gpus 1 --steps 512 --warmup 64                      # headline (default)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one pivot of the hot path: k_select (entering arg-min, ratio-test arg-min, pivot-row
-normalise) + k_update (rank-1 row elimination of the whole tableau).  The tableau is generated on
-the device and is resident in HBM before the timed region starts; nothing crosses PCIe inside it.
-With N > 1 every rank owns one GPU and solves its own LP replica (seed = rank): the path shards
-by independent sub-problems with no data-path collective ("weak" scaling).
-Rank 0 prints ONE JSON line.
+--workload primal (default, BASELINE.json's metric): full-tableau primal-simplex pivots/s on the
+    dense random LP m=4096, n=8192 (4097 x 12289 fp64 tableau, 402.8 MB) and the HBM-roofline
+    fraction of the rank-1 update kernel.  A "step" is one pivot: k_pivot_head (entering arg-min,
+    ratio-test arg-min, pivot-row normalise) + k_update (rank-1 row elimination of the whole
+    tableau).  The tableau is generated on the device and resident in HBM before the timed region;
+    nothing crosses PCIe inside it.  With N > 1 every rank owns one GPU and solves its own LP
+    replica (seed = rank): the path shards by independent sub-problems, no data-path collective.
+--workload revised (BASELINE configs[2]): revised-simplex iterations/s at the same size and the
+    fp64-MFMA B^-1*A product (roofline bound "mfma").
+--workload bb (BASELINE configs[3]): level-synchronous Branch & Bound, sub-trees sharded over the
+    ranks, ONE RCCL all-reduce(MAX) of the incumbent per level; value = sub-problem pivots/s.
 """
 from __future__ import annotations
 
@@ -24,145 +28,26 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F64_PEAK_TFLOPS = 78.6  # MI355X datasheet fp64 matrix (= fp64 vector) peak; the local guide
+#                              has no fp64 MFMA row, tools/mfma_f64_peak.hip probes it on the device
 
 
-def cpu_baseline(m: int, n: int, seed: int, pivots: int):
-    """The C oracle (literal restatement of PrimalSimplexSolver.cs:152-211, gcc -O2
-    -ffp-contract=off, ONE thread like the reference) timed on this host on a bounded sample."""
+def _cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _oracle():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_lib import Oracle
-    orc = Oracle()
-    T, basis = orc.gen_dense_tableau(m, n, seed)
-    t0 = time.perf_counter()
-    st, piv, log = orc.primal_solve(T, basis, pivots)
-    dt = time.perf_counter() - t0
-    return piv / dt, piv, log
-
-
-def main() -> int:
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=512)
-    ap.add_argument("--warmup", type=int, default=64)
-    ap.add_argument("--m", type=int, default=4096)
-    ap.add_argument("--n", type=int, default=8192)
-    ap.add_argument("--variant", type=int, default=0, help="rank-1 update kernel variant (0=auto)")
-    ap.add_argument("--cpu-pivots", type=int, default=-1,
-                    help="pivots of the CPU baseline sample (-1: sized for ~15 s, 0: skip)")
-    ap.add_argument("--no-kernel-timing", action="store_true",
-                    help="replay captured graphs instead of eager launches with HIP events")
-    args = ap.parse_args()
-
-    import torch
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank "
-                             "per GPU)")
-        raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-
-    import lpr_381_group_v22_amd as pkg
-
-    m, n, K, W = args.m, args.n, args.steps, args.warmup
-    R, C = m + 1, n + m + 1
-    bytes_per_pivot = 2 * 8 * R * C  # every tableau element read once + written once (SURVEY 8d)
-    seed = rank  # one LP replica per rank
-
-    eng = pkg.Engine(local_rank)
-    tab = pkg.Tableau.synthetic(eng, m, n, seed)
-    timed = not args.no_kernel_timing
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        eng.sync()
-
-    if W > 0:
-        res = tab.solve(max_pivots=W, time_kernels=False, variant=args.variant)
-        if res.pivots != W:
-            raise SystemExit(f"warm-up ended after {res.pivots} pivots (status {res.status})")
-    k0 = tab.kernel_stats()
-    barrier()
-    t0 = time.perf_counter()
-    res = tab.solve(max_pivots=K, time_kernels=timed, variant=args.variant)
-    barrier()
-    dt = time.perf_counter() - t0
-    if res.pivots != K:
-        raise SystemExit(f"timed region ended after {res.pivots} of {K} pivots "
-                         f"(status {res.status}); pick another seed / fewer steps")
-    k1 = tab.kernel_stats()
-
-    dt_t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if dist is not None:
-        dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
-    dt_max = float(dt_t.item())
-
-    launches = k1[0] - k0[0]
-    kern_ms = (k1[1] - k0[1]) / launches if launches else None
-
-    out = None
-    if rank == 0:
-        value = world * K / dt_max
-        roof = None
-        if kern_ms:
-            achieved = bytes_per_pivot / (kern_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": "k_update (rank-1 row elimination)",
-                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                    "bytes_per_launch": bytes_per_pivot,
-                    "avg_launch_ms": round(kern_ms, 6), "launches": launches,
-                    "event_sampling": "every 4th k_update launch of the timed region",
-                    "traffic": None}
-            roof.update(_pmc_traffic(m, n))
-        cpu = None
-        if world == 1 and args.cpu_pivots != 0:
-            cp = args.cpu_pivots
-            if cp < 0:
-                # ~16*R*C bytes per pivot at roughly 4 GB/s on one core -> aim at ~15 s
-                cp = max(4, min(2000, int(15.0 / (bytes_per_pivot / 4.0e9))))
-            cpu_rate, cpu_piv, cpu_log = cpu_baseline(m, n, 0, cp)
-            gpu_log = tab.pivot_log(cap=cpu_piv)
-            cpu = {"value": round(cpu_rate, 3), "unit": "pivots/s", "cores": 1, "kind": "port",
-                   "sample": f"first {cpu_piv} pivots of the same LP (m={m}, n={n}, seed 0) by "
-                             f"the C oracle of PrimalSimplexSolver.cs:152-211, 1 thread, "
-                             f"snapshots off; cpu: {_cpu_model()}, {os.cpu_count()} logical",
-                   "pivot_log_matches_gpu": bool(
-                       (gpu_log[:min(len(gpu_log), len(cpu_log))]
-                        == cpu_log[:min(len(gpu_log), len(cpu_log))]).all())}
-        out = {
-            "metric": "simplex pivots/sec on 4096x8192 fp64 tableau; % HBM roofline",
-            "value": round(value, 2), "unit": "pivots/s", "n_gpus": world, "steps": K,
-            "warmup": W, "ms_per_step": round(dt_max * 1e3 / K, 6), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"dense random LP m={m} n={n} fp64, full-tableau primal "
-                                   f"simplex pivots on the {R}x{C} tableau "
-                                   f"({R * C * 8 / 1e6:.1f} MB), one LP replica per GPU",
-                       "m": m, "n": n, "rows": R, "cols": C, "seed": "rank",
-                       "parallelism": f"replica{world}", "update_variant": args.variant,
-                       "launch": "eager+events" if timed else "hipGraph"},
-            "roofline": roof, "cpu_baseline": cpu,
-        }
-    tab.destroy()
-    eng.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-    if out is not None:
-        print(json.dumps(out), flush=True)
-    return 0
+    return Oracle()
 
 
 def _pmc_traffic(m: int, n: int) -> dict:
@@ -184,15 +69,278 @@ def _pmc_traffic(m: int, n: int) -> dict:
     return best
 
 
-def _cpu_model() -> str:
-    try:
-        with open("/proc/cpuinfo") as f:
-            for ln in f:
-                if ln.startswith("model name"):
-                    return ln.split(":", 1)[1].strip()
-    except OSError:
-        pass
-    return "unknown"
+class Dist:
+    """torch.distributed plumbing (backend nccl == RCCL over xGMI); a no-op at world size 1."""
+
+    def __init__(self, args):
+        import torch
+        self.torch = torch
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.world != args.gpus:
+            if self.world == 1 and args.gpus > 1:
+                raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one "
+                                 "rank per GPU)")
+            raise SystemExit(f"WORLD_SIZE={self.world} does not match --gpus {args.gpus}")
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
+        torch.cuda.set_device(self.local_rank)
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend="nccl",
+                                    device_id=torch.device("cuda", self.local_rank))
+            self.dist = dist
+
+    def barrier(self, eng=None):
+        if self.dist is not None:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+        if eng is not None:
+            eng.sync()
+
+    def max(self, v: float) -> float:
+        t = self.torch.tensor([v], dtype=self.torch.float64, device="cuda")
+        if self.dist is not None:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum(self, v: float) -> float:
+        t = self.torch.tensor([v], dtype=self.torch.float64, device="cuda")
+        if self.dist is not None:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return float(t.item())
+
+    def finish(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------ primal
+def run_primal(args, D: Dist):
+    import lpr_381_group_v22_amd as pkg
+    m, n, K, W = args.m, args.n, args.steps, args.warmup
+    R, C = m + 1, n + m + 1
+    bytes_per_pivot = 2 * 8 * R * C  # every tableau element read once + written once (SURVEY 8d)
+    eng = pkg.Engine(D.local_rank)
+    tab = pkg.Tableau.synthetic(eng, m, n, D.rank)  # one LP replica per rank (seed = rank)
+    timed = not args.no_kernel_timing
+    if W > 0:
+        res = tab.solve(max_pivots=W, time_kernels=False, variant=args.variant)
+        if res.pivots != W:
+            raise SystemExit(f"warm-up ended after {res.pivots} pivots (status {res.status})")
+    k0 = tab.kernel_stats()
+    D.barrier(eng)
+    t0 = time.perf_counter()
+    res = tab.solve(max_pivots=K, time_kernels=timed, variant=args.variant)
+    D.barrier(eng)
+    dt = time.perf_counter() - t0
+    if res.pivots != K:
+        raise SystemExit(f"timed region ended after {res.pivots} of {K} pivots "
+                         f"(status {res.status}); pick another seed / fewer steps")
+    k1 = tab.kernel_stats()
+    dt_max = D.max(dt)
+    launches = k1[0] - k0[0]
+    kern_ms = (k1[1] - k0[1]) / launches if launches else None
+
+    out = None
+    if D.rank == 0:
+        value = D.world * K / dt_max
+        roof = None
+        if kern_ms:
+            achieved = bytes_per_pivot / (kern_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": "k_update (rank-1 row elimination)",
+                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                    "bytes_per_launch": bytes_per_pivot,
+                    "avg_launch_ms": round(kern_ms, 6), "launches": launches,
+                    "event_sampling": "every 4th k_update launch of the timed region",
+                    "traffic": None}
+            roof.update(_pmc_traffic(m, n))
+        cpu = None
+        if D.world == 1 and args.cpu_pivots != 0:
+            cp = args.cpu_pivots
+            if cp < 0:  # ~16*R*C bytes per pivot at roughly 4 GB/s on one core -> aim at ~15 s
+                cp = max(4, min(2000, int(15.0 / (bytes_per_pivot / 4.0e9))))
+            orc = _oracle()
+            T, basis = orc.gen_dense_tableau(m, n, 0)
+            c0 = time.perf_counter()
+            st, cpu_piv, cpu_log = orc.primal_solve(T, basis, cp)
+            cdt = time.perf_counter() - c0
+            gpu_log = tab.pivot_log(cap=cpu_piv)
+            q = min(len(gpu_log), len(cpu_log))
+            cpu = {"value": round(cpu_piv / cdt, 3), "unit": "pivots/s", "cores": 1,
+                   "kind": "port",
+                   "sample": f"first {cpu_piv} pivots of the same LP (m={m}, n={n}, seed 0) by "
+                             f"the C oracle of PrimalSimplexSolver.cs:152-211, 1 thread, "
+                             f"snapshots off; cpu: {_cpu_model()}, {os.cpu_count()} logical",
+                   "pivot_log_matches_gpu": bool((gpu_log[:q] == cpu_log[:q]).all())}
+        out = {
+            "metric": "simplex pivots/sec on 4096x8192 fp64 tableau; % HBM roofline",
+            "value": round(value, 2), "unit": "pivots/s", "n_gpus": D.world, "steps": K,
+            "warmup": W, "ms_per_step": round(dt_max * 1e3 / K, 6), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"dense random LP m={m} n={n} fp64, full-tableau primal "
+                                   f"simplex pivots on the {R}x{C} tableau "
+                                   f"({R * C * 8 / 1e6:.1f} MB), one LP replica per GPU",
+                       "m": m, "n": n, "rows": R, "cols": C, "seed": "rank",
+                       "parallelism": f"replica{D.world}", "update_variant": args.variant,
+                       "launch": "eager+events" if timed else "hipGraph"},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+    tab.destroy()
+    eng.close()
+    return out
+
+
+# ------------------------------------------------------------------------------------ revised
+def run_revised(args, D: Dist):
+    import lpr_381_group_v22_amd as pkg
+    m, n, K, W = args.m, args.n, args.steps, args.warmup
+    eng = pkg.Engine(D.local_rank)
+    st = pkg.RevisedState.synthetic(eng, m, n, D.rank)
+    if W > 0:
+        st.solve(max_pivots=W)
+    D.barrier(eng)
+    t0 = time.perf_counter()
+    res = st.solve(max_pivots=K)
+    D.barrier(eng)
+    dt = time.perf_counter() - t0
+    if res.iterations != K:
+        raise SystemExit(f"timed region ended after {res.iterations} of {K} iterations")
+    dt_max = D.max(dt)
+    best = None
+    for _ in range(5):  # the snapshot product B^-1 * A of CaptureSnapshot (:360), on MFMA
+        _, ms = st.binv_a(fetch=False)
+        best = ms if best is None else min(best, ms)
+    flop = 2.0 * m * m * n
+    out = None
+    if D.rank == 0:
+        tf = flop / (best * 1e-3) / 1e12
+        cpu = None
+        if D.world == 1 and args.cpu_pivots != 0:
+            orc = _oracle()
+            c, A, b = orc.gen_dense_lp(m, n, 0)
+            cp = args.cpu_pivots if args.cpu_pivots > 0 else max(2, min(200, int(2.0e9 / (m * (m + n)) / 6)))
+            c0 = time.perf_counter()
+            ref = orc.revised_solve(c, A, b, False, max_iter=cp)
+            cdt = time.perf_counter() - c0
+            log = st.log(cap=cp)
+            q = min(len(log), len(ref["log"]))
+            cpu = {"value": round(ref["iterations"] / cdt, 3), "unit": "iterations/s", "cores": 1,
+                   "kind": "port",
+                   "sample": f"first {ref['iterations']} iterations of the same LP by the C "
+                             f"oracle of RevisedPrimalSimplexSolver.cs:82-275 (snapshot GEMM "
+                             f"off), 1 thread; cpu: {_cpu_model()}",
+                   "pivot_log_matches_gpu": bool((log[:q] == ref["log"][:q]).all())}
+        out = {
+            "metric": "revised simplex iterations/sec on m=4096 n=8192 fp64; B^-1*A TFLOP/s",
+            "value": round(D.world * K / dt_max, 2), "unit": "iterations/s", "n_gpus": D.world,
+            "steps": K, "warmup": W, "ms_per_step": round(dt_max * 1e3 / K, 6),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"dense random LP m={m} n={n} fp64, revised primal simplex "
+                                   f"(order-faithful GEMVs, E*B^-1 update) + B^-1*A on fp64 MFMA",
+                       "m": m, "n": n, "parallelism": f"replica{D.world}"},
+            "roofline": {"bound": "mfma", "kernel": "k_rev_gemm (B^-1 * A, mfma_f64_16x16x4)",
+                         "achieved": round(tf, 2), "peak": MFMA_F64_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(tf / MFMA_F64_PEAK_TFLOPS, 4),
+                         "flop_per_launch": flop, "launch_ms": round(best, 4), "traffic": None},
+            "cpu_baseline": cpu,
+        }
+    st.destroy()
+    eng.close()
+    return out
+
+
+# ------------------------------------------------------------------------------------ bb
+def bb_instance(nvars: int, ncons: int, seed: int):
+    """Seeded binary programme in the reference's option-3 shape: max c.x, A x <= b, plus the
+    n rows x_i <= 1 that Program.cs:372-382 appends."""
+    import numpy as np
+    rng = np.random.RandomState(seed)
+    c = rng.randint(1, 20, size=nvars).astype(float)
+    A = rng.randint(1, 15, size=(ncons, nvars)).astype(float)
+    b = np.floor(A.sum(axis=1) * rng.uniform(0.3, 0.6, size=ncons))
+    return c, A, b
+
+
+def run_bb(args, D: Dist):
+    import numpy as np
+    import lpr_381_group_v22_amd as pkg
+    from lpr_381_group_v22_amd import Constraint
+    nv, nc, levels = args.bb_vars, args.bb_cons, args.bb_levels
+    eng = pkg.Engine(D.local_rank)
+    c, A, b = bb_instance(nv, nc, 7)
+    cons = [Constraint(A[i].tolist(), "<=", float(b[i])) for i in range(nc)]
+    for i in range(nv):  # Program.cs:372-382
+        co = [0.0] * (nv + 3)
+        co[i] = 1.0
+        co[nv + 1] = 1.0
+        cons.append(Constraint(co, "<=", 1.0))
+    primal = pkg.PrimalSimplexSolver(c.tolist(), cons, True, engine=eng, snapshots="none")
+    primal.Solve()
+    tree = pkg.BranchBoundTree.from_tableau(primal.tableau, nv, max_depth=levels + 2)
+    if D.dist is not None:
+        arm, gather = pkg.torch_collectives()
+    else:
+        arm, gather = None, None
+    D.barrier(eng)
+    t0 = time.perf_counter()
+    res = pkg.solve_level_synchronous(tree, nv, rank=D.rank, world=D.world, all_reduce_max=arm,
+                                      gather=gather, max_levels=levels)
+    D.barrier(eng)
+    dt = time.perf_counter() - t0
+    dt_max = D.max(dt)
+    out = None
+    if D.rank == 0:
+        out = {
+            "metric": "Branch&Bound sub-problem pivots/sec (level-synchronous, sub-trees sharded)",
+            "value": round(res["pivots"] / dt_max, 2), "unit": "pivots/s", "n_gpus": D.world,
+            "steps": res["levels"], "warmup": 0,
+            "ms_per_step": round(dt_max * 1e3 / max(res["levels"], 1), 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"binary programme {nv} vars, {nc}+{nv} rows (root tableau "
+                                   f"{nc + nv + 1}x{2 * nv + nc + 1}), {levels} levels, "
+                                   f"pruning off, cap lifted",
+                       "nodes_processed": res["processed"], "pivots": res["pivots"],
+                       "nodes_per_s": round(res["processed"] / dt_max, 1),
+                       "incumbent_z": res["z"] if res["found"] else None, "collective": "1 all-reduce(MAX, 16 B)/level",
+                       "parallelism": f"subtree{D.world}"},
+            "roofline": None, "cpu_baseline": None,
+        }
+    tree.destroy()
+    eng.close()
+    return out
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=512)
+    ap.add_argument("--warmup", type=int, default=64)
+    ap.add_argument("--workload", choices=["primal", "revised", "bb"], default="primal")
+    ap.add_argument("--m", type=int, default=4096)
+    ap.add_argument("--n", type=int, default=8192)
+    ap.add_argument("--variant", type=int, default=0, help="rank-1 update kernel variant (0=auto)")
+    ap.add_argument("--cpu-pivots", type=int, default=-1,
+                    help="pivots of the CPU baseline sample (-1: sized for ~15 s, 0: skip)")
+    ap.add_argument("--no-kernel-timing", action="store_true",
+                    help="replay captured graphs instead of eager launches with HIP events")
+    ap.add_argument("--bb-vars", type=int, default=128)
+    ap.add_argument("--bb-cons", type=int, default=8)
+    ap.add_argument("--bb-levels", type=int, default=9)
+    args = ap.parse_args()
+    D = Dist(args)
+    out = {"primal": run_primal, "revised": run_revised, "bb": run_bb}[args.workload](args, D)
+    D.finish()
+    if out is not None:
+        print(json.dumps(out), flush=True)
+    return 0
 
 
 if __name__ == "__main__":

@@ -1,0 +1,86 @@
+"""CPU tests of the host-side text plumbing: model-file parser (IO/InputFileParser.cs), .NET number
+formatting used by the snapshots / result file.  PARITY UNPINNED: the reference commits no output
+text; the expected strings below are .NET Framework's documented behaviour for these specifiers."""
+import os
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import lpr_381_group_v22_amd as p
+    return p
+
+
+def test_parser_reads_the_sample_model(pkg):
+    p = pkg.InputFileParser()
+    p.ReadInputFile(os.path.join(HERE, "golden", "TextFile.txt"))
+    assert p.ProblemType == "max"
+    assert p.ObjectiveCoefficients == [2, 3, 3, 5, 2, 4]
+    assert len(p.Constraints) == 1
+    assert p.Constraints[0].Coefficients == [11, 8, 6, 14, 10, 10]
+    assert p.Constraints[0].Relation == "<=" and p.Constraints[0].RHS == 40
+    assert p.SignRestrictions == ["bin"] * 6
+
+
+def test_parser_rejects_short_and_missing_files(pkg, tmp_path, capsys):
+    p = pkg.InputFileParser()
+    p.ReadInputFile(str(tmp_path / "nope.txt"))
+    assert p.ProblemType is None and "can't find your file" in capsys.readouterr().out
+    f = tmp_path / "short.txt"
+    f.write_text("max 1 2\n1 1 <= 3\n")
+    p.ReadInputFile(str(f))
+    assert p.ProblemType is None and "not formatted correctly" in capsys.readouterr().out
+
+
+def test_parser_relations_and_min(pkg, tmp_path):
+    f = tmp_path / "m.txt"
+    f.write_text("MIN +2 -3.5 +4\n+1 +2   +3 <= 10\n+3 +2 +1 >= 15\n1 0 0 = 2\n+ - urs\n")
+    p = pkg.InputFileParser()
+    p.ReadInputFile(str(f))
+    assert p.ProblemType == "min" and p.ObjectiveCoefficients == [2.0, -3.5, 4.0]
+    assert [c.Relation for c in p.Constraints] == ["<=", ">=", "="]
+    assert p.Constraints[0].Coefficients == [1.0, 2.0, 3.0]
+    assert p.SignRestrictions == ["+", "-", "urs"]
+
+
+def test_dotnet_fixed_point_formatting():
+    from lpr_381_group_v22_amd import table_iteration_formater as f
+    assert f.F3(15.4) == "15.400" and f.F3(-0.0) == "0.000" and f.F3(-0.0004) == "0.000"
+    assert f.F3(2.0005) == "2.001"      # 15-digit decimal first, then half away from zero
+    assert f.F3(0.0005) == "0.001" and f.F3(-1.2345) == "-1.235" and f.F3(1e6) == "1000000.000"
+    assert f.F6(15.4) == "15.400000"
+    assert f.N3(15.399999999999999) == "15.4" and f.N3(0.19999999999999973) == "0.2"
+    assert f.N3(1e-13) == "0" and f.N3(-2.0) == "-2" and f.N3(0.0005) == "0.001"
+    assert f.N3(1234.5678) == "1234.568" and f.N3(-0.1234) == "-0.123"
+
+
+def test_dotnet_general_formatting():
+    from lpr_381_group_v22_amd.program import dotnet_double_to_string as g
+    assert g(40.0) == "40" and g(0.5) == "0.5" and g(-11.0) == "-11" and g(1e-5) == "1E-05"
+    assert g(1e20) == "1E+20" and g(0.1 + 0.2) == "0.3" and g(-0.0) == "0"
+
+
+def test_canonical_form_text(pkg):
+    from lpr_381_group_v22_amd.program import canonical_form_for_file
+    p = pkg.InputFileParser()
+    p.ReadInputFile(os.path.join(HERE, "golden", "TextFile.txt"))
+    s = canonical_form_for_file(p.ProblemType, p.ObjectiveCoefficients, p.Constraints,
+                                p.SignRestrictions)
+    assert "Z -2x1 -3x2 -3x3 -5x4 -2x5 -4x6 = 0\n" in s
+    assert "+ 11x1 + 8x2 + 6x3 + 14x4 + 10x5 + 10x6 + S1 = 40\n" in s
+    assert "Sign Restrictions: x1: bin x2: bin" in s
+
+
+def test_table_format_layout():
+    import numpy as np
+    from lpr_381_group_v22_amd import table_iteration_formater as f
+    t = np.array([[-2.0, -3.0, 0.0, 0.0], [1.0, 2.0, 1.0, 10.0]])
+    s = f.Format(t, 2, "Initial Tableau")
+    lines = s.split("\r\n")
+    assert lines[0] == "\nInitial Tableau:" and lines[1] == "-" * 80
+    assert lines[2] == "Table\tx1\tx2\tt1\tRHS"
+    assert lines[3] == "Z\t-2.000\t-3.000\t0.000\t0.000\t"
+    assert lines[4] == "1\t1.000\t2.000\t1.000\t10.000\t"

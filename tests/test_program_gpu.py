@@ -1,0 +1,72 @@
+"""GPU test of the solver-selection surface (Program.cs options 1-3) on the reference's sample
+model: same text file in, same numbers and result-file layout out."""
+import os
+import shutil
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def load(pkg):
+    p = pkg.InputFileParser()
+    p.ReadInputFile(os.path.join(HERE, "golden", "TextFile.txt"))
+    return p
+
+
+def test_option1_primal(engine, tmp_path):
+    import lpr_381_group_v22_amd as pkg
+    from lpr_381_group_v22_amd.program import run_option
+    p = load(pkg)
+    out = str(tmp_path / "data" / "output_results.txt")
+    r = run_option(p, "1", out, engine=engine)
+    assert r["z"] == 15.4 and len(p.Constraints) == 7  # the parser's own list grew (Program.cs:123)
+    text = open(out, encoding="utf-8-sig").read()
+    assert "Solver: Primal Simplex Algorithm" in text and "Problem type: max" in text
+    assert "=== Canonical Form ===" in text and "=== Iteration Snapshots ===" in text
+    assert "--- Iteration 8 ---" in text  # initial + 6 pivots + final block
+    assert "Z* = 15.4\r\n" in text and "x5 = 0.2\r\n" in text and "x1 = 0\r\n" in text
+    assert "Final Tableau (Optimal):" in text and "Z = 15.400000" in text
+    # choosing the option again appends the bound rows again (reference behaviour)
+    run_option(p, "1", out, engine=engine)
+    assert len(p.Constraints) == 13
+
+
+def test_option2_revised(engine, tmp_path):
+    import lpr_381_group_v22_amd as pkg
+    from lpr_381_group_v22_amd.program import run_option
+    p = load(pkg)
+    out = str(tmp_path / "output_results.txt")
+    r = run_option(p, "2", out, engine=engine)
+    assert r["z"] == 15.399999999999999 and len(p.Constraints) == 1  # option 2 works on copies
+    text = open(out, encoding="utf-8-sig").read()
+    assert "Solver: Revised Primal Simplex Algorithm (T-*)" in text
+    assert "Z* = 15.4\r\n" in text and "x5 = 0.2\r\n" in text
+
+
+def test_option3_branch_and_bound(engine, tmp_path):
+    import lpr_381_group_v22_amd as pkg
+    from lpr_381_group_v22_amd.program import run_option
+    p = load(pkg)
+    out = str(tmp_path / "output_results.txt")
+    r = run_option(p, "3", out, engine=engine)
+    assert r["z"] == 15.0 and r["x"] == [0.0, 1.0, 1.0, 1.0, 0.0, 1.0]
+    text = open(out, encoding="utf-8-sig").read()
+    assert "Solver: Branch and Bound Simplex Algorithm" in text and "=== Solver Log ===" in text
+    assert "=== Branch & Bound Result ===" in text
+    assert "Z* = 15\r\n" in text and "x2 = 1\r\n" in text and "x1 = 0\r\n" in text
+
+
+def test_min_problem_redirect(engine, tmp_path, capsys):
+    import lpr_381_group_v22_amd as pkg
+    from lpr_381_group_v22_amd.program import run_option
+    f = tmp_path / "min.txt"
+    f.write_text("min +3 +2\n+1 +1 <= 4\n+ +\n")
+    p = pkg.InputFileParser()
+    p.ReadInputFile(str(f))
+    r = run_option(p, "1", str(tmp_path / "o.txt"), engine=engine)  # Program.cs:92-99
+    assert r == {"skipped": True}
+    assert "Please use Option 2" in capsys.readouterr().out
+    r = run_option(p, "2", str(tmp_path / "o.txt"), engine=engine)
+    assert r["z"] == 0.0 and r["x"] == [0.0, 0.0]
