@@ -22,7 +22,7 @@ def test_option1_primal(engine, tmp_path):
     out = str(tmp_path / "data" / "output_results.txt")
     r = run_option(p, "1", out, engine=engine)
     assert r["z"] == 15.4 and len(p.Constraints) == 7  # the parser's own list grew (Program.cs:123)
-    text = open(out, encoding="utf-8-sig").read()
+    text = open(out, encoding="utf-8-sig", newline="").read()
     assert "Solver: Primal Simplex Algorithm" in text and "Problem type: max" in text
     assert "=== Canonical Form ===" in text and "=== Iteration Snapshots ===" in text
     assert "--- Iteration 8 ---" in text  # initial + 6 pivots + final block
@@ -40,7 +40,7 @@ def test_option2_revised(engine, tmp_path):
     out = str(tmp_path / "output_results.txt")
     r = run_option(p, "2", out, engine=engine)
     assert r["z"] == 15.399999999999999 and len(p.Constraints) == 1  # option 2 works on copies
-    text = open(out, encoding="utf-8-sig").read()
+    text = open(out, encoding="utf-8-sig", newline="").read()
     assert "Solver: Revised Primal Simplex Algorithm (T-*)" in text
     assert "Z* = 15.4\r\n" in text and "x5 = 0.2\r\n" in text
 
@@ -52,7 +52,7 @@ def test_option3_branch_and_bound(engine, tmp_path):
     out = str(tmp_path / "output_results.txt")
     r = run_option(p, "3", out, engine=engine)
     assert r["z"] == 15.0 and r["x"] == [0.0, 1.0, 1.0, 1.0, 0.0, 1.0]
-    text = open(out, encoding="utf-8-sig").read()
+    text = open(out, encoding="utf-8-sig", newline="").read()
     assert "Solver: Branch and Bound Simplex Algorithm" in text and "=== Solver Log ===" in text
     assert "=== Branch & Bound Result ===" in text
     assert "Z* = 15\r\n" in text and "x2 = 1\r\n" in text and "x1 = 0\r\n" in text
