@@ -76,6 +76,7 @@ struct lpr_tableau {
     lpr_engine* eng = nullptr;
     int rows = 0, cols = 0, ld = 0;  // ld = cols rounded up to kLdAlign
     double* T = nullptr;             // rows x ld, row-major, padding columns kept at 0
+    double* T2 = nullptr;            // second buffer of the fused small-tableau path (lazy)
     double* rowbuf = nullptr;        // ld doubles: normalised pivot row
     double* colbuf = nullptr;        // rows doubles: pivot column before the update
     double* next_col = nullptr;      // rows doubles: column next_e of the tableau AFTER the update
@@ -99,4 +100,5 @@ struct lpr_tableau {
     hipGraphExec_t graph = nullptr;
     int graph_batch = 0;
     int graph_variant = -1;
+    const double* graph_T = nullptr;  // T at capture time (the fused path alternates T / T2)
 };

@@ -30,6 +30,7 @@ void launch_pivot_head(lpr_tableau* t);
 void launch_update(lpr_tableau* t, int variant, int check_status, int dump_next);
 int num_update_variants();
 void launch_extract(lpr_tableau* t, int n, double* x);
+void launch_pivot_fused(lpr_tableau* t, const double* in, double* out);
 void launch_build(lpr_tableau* t, int n, int m, const double* d_obj, const double* d_A, int lda,
                   const int32_t* d_ncoef, const int8_t* d_rel, const double* d_rhs, int is_max);
 void launch_synthetic(lpr_tableau* t, int m, int n, uint64_t seed);
@@ -105,6 +106,7 @@ static void release_device(lpr_tableau* t) {
     for (hipEvent_t ev : t->ev) hipEventDestroy(ev);
     t->ev.clear();
     hipFree(t->T);
+    hipFree(t->T2);
     hipFree(t->rowbuf);
     hipFree(t->colbuf);
     hipFree(t->next_col);
@@ -119,6 +121,7 @@ static void release_device(lpr_tableau* t) {
     if (t->h_scratch_i) hipHostFree(t->h_scratch_i);
     t->T = t->rowbuf = t->colbuf = t->xbuf = t->next_col = t->next_rhs = nullptr;
     t->zparts = nullptr;
+    t->T2 = nullptr;
     t->basis = t->log = t->scratch_i = t->h_scratch_i = nullptr;
     t->state = t->h_state = nullptr;
 }
@@ -162,6 +165,121 @@ static int default_batch(const lpr_tableau* t) {
     if (b < 8) b = 8;
     if (b > 512) b = 512;
     return b;
+}
+
+// Small tableaux (<= kFusedBytes): one k_pivot_fused launch per pivot, ping-pong between T and
+// T2.  opts.variant == 0x7fff forces the two-kernel path (tests), 0x7ffe forces the fused one.
+static constexpr size_t kFusedBytes = (size_t)16 << 20;
+
+static bool use_fused(const lpr_tableau* t, const lpr_solve_opts& o) {
+    if (o.time_kernels) return false;
+    if (o.variant == 0x7fff) return false;
+    if (o.variant == 0x7ffe) return true;
+    if (o.variant != 0) return false;
+    return (size_t)t->rows * t->ld * sizeof(double) <= kFusedBytes;
+}
+
+static int solve_fused(lpr_tableau* t, const lpr_solve_opts& o, lpr_solve_result* res) {
+    lpr_engine* e = t->eng;
+    hipStream_t s = e->stream;
+    const size_t tbytes = (size_t)t->rows * t->ld * sizeof(double);
+    if (!t->T2) {
+        LPR_HIP(hipMalloc(&t->T2, tbytes));
+        LPR_HIP(hipMemsetAsync(t->T2, 0, tbytes, s));
+    }
+    int batch = o.batch > 0 ? o.batch : default_batch(t);
+    batch = (batch + 1) & ~1;  // even: a full batch leaves the tableau in the buffer it started in
+    const int64_t start_iter = t->total_pivots;
+    const int64_t max_iter = o.max_pivots > 0 ? start_iter + o.max_pivots : 0;
+    PivotState* hs = t->h_state;
+    hs->status = kRunning;
+    hs->iter = start_iter;
+    hs->max_iter = 0;  // the host enforces the limit on this path
+    hs->log_cap = t->log_cap;
+    LPR_HIP(hipMemcpyAsync(&t->state->status, &hs->status, sizeof(int32_t), hipMemcpyHostToDevice,
+                           s));
+    LPR_HIP(hipMemcpyAsync(&t->state->iter, &hs->iter, 3 * sizeof(int64_t),
+                           hipMemcpyHostToDevice, s));
+    int status = kRunning;
+    int64_t iter = start_iter;
+    while (status == kRunning) {
+        int nb = batch;
+        if (max_iter > 0 && max_iter - iter < nb) nb = (int)(max_iter - iter);
+        if (nb <= 0) break;
+        int rc = ensure_log(t, iter + nb + 1);
+        if (rc != LPR_OK_OPTIMAL) return rc;
+        if (t->log_cap != hs->log_cap) {
+            hs->log_cap = t->log_cap;
+            LPR_HIP(hipMemcpyAsync(&t->state->log_cap, &hs->log_cap, sizeof(int64_t),
+                                   hipMemcpyHostToDevice, s));
+        }
+        const bool full = (nb == batch);
+        if (full) {  // replay a captured batch (valid for the current T / T2 orientation)
+            if (!t->graph || t->graph_batch != nb || t->graph_variant != -2 ||
+                t->graph_T != t->T) {
+                drop_graph(t);
+                hipGraph_t g = nullptr;
+                LPR_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+                for (int k = 0; k < nb; ++k)
+                    launch_pivot_fused(t, (k & 1) ? t->T2 : t->T, (k & 1) ? t->T : t->T2);
+                LPR_HIP(hipStreamEndCapture(s, &g));
+                hipError_t ierr = hipGraphInstantiate(&t->graph, g, nullptr, nullptr, 0);
+                hipGraphDestroy(g);
+                if (ierr != hipSuccess) {
+                    t->graph = nullptr;
+                    set_error("hipGraphInstantiate failed: %s", hipGetErrorString(ierr));
+                    return LPR_DEVICE_ERROR;
+                }
+                t->graph_batch = nb;
+                t->graph_variant = -2;
+                t->graph_T = t->T;
+            }
+            LPR_HIP(hipGraphLaunch(t->graph, s));
+        } else {
+            for (int k = 0; k < nb; ++k)
+                launch_pivot_fused(t, (k & 1) ? t->T2 : t->T, (k & 1) ? t->T : t->T2);
+        }
+        LPR_HIP(hipGetLastError());
+        LPR_HIP(hipMemcpyAsync(hs, t->state, sizeof(PivotState), hipMemcpyDeviceToHost, s));
+        LPR_HIP(hipStreamSynchronize(s));
+        const int64_t done = hs->iter - iter;
+        if (done & 1) {  // an odd number of pivots happened: the live tableau is in T2
+            double* tmp = t->T;
+            t->T = t->T2;
+            t->T2 = tmp;
+        }
+        iter = hs->iter;
+        status = hs->status;
+        if (status == kRunning && done != nb) {
+            set_error("fused pivot loop lost a launch (done %lld of %d)", (long long)done, nb);
+            return LPR_DEVICE_ERROR;
+        }
+    }
+    if (status == kRunning) {  // stopped by the pivot limit: classify the current tableau
+        launch_select(t, kSelEnter, -1, -1, t->scratch_i);
+        LPR_HIP(hipMemcpyAsync(t->h_scratch_i, t->scratch_i, 4 * sizeof(int32_t),
+                               hipMemcpyDeviceToHost, s));
+        LPR_HIP(hipStreamSynchronize(s));
+        const int ec = t->h_scratch_i[0];
+        if (ec < 0) status = LPR_OK_OPTIMAL;
+        else {
+            launch_select(t, kSelLeave, ec, -1, t->scratch_i);
+            LPR_HIP(hipMemcpyAsync(t->h_scratch_i, t->scratch_i, 4 * sizeof(int32_t),
+                                   hipMemcpyDeviceToHost, s));
+            LPR_HIP(hipStreamSynchronize(s));
+            status = t->h_scratch_i[1] < 0 ? LPR_UNBOUNDED : LPR_PIVOT_LIMIT;
+        }
+    }
+    t->total_pivots = iter;
+    res->status = status;
+    res->reserved = 0;
+    res->pivots = iter - start_iter;
+    res->total_pivots = iter;
+    double z = 0.0;
+    LPR_HIP(hipMemcpyAsync(&z, t->T + (t->cols - 1), sizeof(double), hipMemcpyDeviceToHost, s));
+    LPR_HIP(hipStreamSynchronize(s));
+    res->z = z;
+    return status;
 }
 
 }  // namespace lpr
@@ -402,7 +520,8 @@ int lpr_primal_solve(lpr_tableau* t, const lpr_solve_opts* opts, lpr_solve_resul
     hipStream_t s = e->stream;
     LPR_HIP(hipSetDevice(e->device));
 
-    const int variant = o.variant > 0 ? o.variant - 1 : default_variant(t);
+    if (use_fused(t, o)) return solve_fused(t, o, res);
+    const int variant = (o.variant > 0 && o.variant < 0x7000) ? o.variant - 1 : default_variant(t);
     int batch = o.batch > 0 ? o.batch : default_batch(t);
     const bool timed = o.time_kernels != 0;
     const int64_t start_iter = t->total_pivots;

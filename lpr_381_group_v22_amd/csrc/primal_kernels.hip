@@ -470,7 +470,30 @@ __global__ __launch_bounds__(1024) void k_pivot_head(const double* __restrict__ 
 // of the normalised pivot row in registers for the whole tile, the per-row factor f_i is a
 // wave-uniform scalar load, and all TR*VPT 16-byte loads of a lane are issued before the first
 // store so a wave has TR*VPT KiB in flight.
-template <int TR, int VPT, bool FULL>
+typedef double v2d_t __attribute__((ext_vector_type(2)));
+
+// NT bit 0: non-temporal loads of the tableau, bit 1: non-temporal stores (tuning variants)
+template <int NT>
+__device__ __forceinline__ double2 ld_tab(const double2* p) {
+    if (NT & 1) {
+        const v2d_t v = __builtin_nontemporal_load(reinterpret_cast<const v2d_t*>(p));
+        return make_double2(v.x, v.y);
+    }
+    return *p;
+}
+template <int NT>
+__device__ __forceinline__ void st_tab(double2* p, double2 o) {
+    if (NT & 2) {
+        v2d_t v;
+        v.x = o.x;
+        v.y = o.y;
+        __builtin_nontemporal_store(v, reinterpret_cast<v2d_t*>(p));
+    } else {
+        *p = o;
+    }
+}
+
+template <int TR, int VPT, bool FULL, int NT>
 __device__ __forceinline__ void update_tile(double2* __restrict__ T2, int ld2, int R, int r,
                                             const double2* __restrict__ prow2,
                                             const double* __restrict__ colbuf, int i0,
@@ -492,7 +515,7 @@ __device__ __forceinline__ void update_tile(double2* __restrict__ T2, int ld2, i
         if (FULL || i < R) {
 #pragma unroll
             for (int v = 0; v < VPT; ++v)
-                if (ok[v]) x[k][v] = T2[(size_t)i * ld2 + c2base + v * 256];
+                if (ok[v]) x[k][v] = ld_tab<NT>(&T2[(size_t)i * ld2 + c2base + v * 256]);
         }
     }
     // While the tile is in flight: which lanes own the next entering column / the RHS column?
@@ -523,7 +546,7 @@ __device__ __forceinline__ void update_tile(double2* __restrict__ T2, int ld2, i
                     o.x = x[k][v].x - px;           // ... then the difference (:208)
                     o.y = x[k][v].y - py;
                     if (is_r) o = pr[v];            // the pivot row keeps the normalised values
-                    T2[(size_t)i * ld2 + c2base + v * 256] = o;
+                    st_tab<NT>(&T2[(size_t)i * ld2 + c2base + v * 256], o);
                     if (v == dump_e) next_col[i] = (ne & 1) ? o.y : o.x;
                     if (v == dump_rhs) next_rhs[i] = (rhs & 1) ? o.y : o.x;
                 }
@@ -532,7 +555,7 @@ __device__ __forceinline__ void update_tile(double2* __restrict__ T2, int ld2, i
     }
 }
 
-template <int TR, int VPT>
+template <int TR, int VPT, int NT>
 __global__ __launch_bounds__(256) void k_update(double* __restrict__ T, int ld, int R, int C,
                                                 const double* __restrict__ rowbuf,
                                                 const double* __restrict__ colbuf,
@@ -559,11 +582,116 @@ __global__ __launch_bounds__(256) void k_update(double* __restrict__ T, int ld, 
     // interior tiles (the common case) run without any per-element guard
     const bool full = (i0 + TR <= R) && ((ct + 1) * (256 * VPT) <= ld2);
     if (full)
-        update_tile<TR, VPT, true>(T2, ld2, R, r, prow2, colbuf, i0, c2base, zbank, G, C - 1,
+        update_tile<TR, VPT, true, NT>(T2, ld2, R, r, prow2, colbuf, i0, c2base, zbank, G, C - 1,
                                    next_col, next_rhs);
     else
-        update_tile<TR, VPT, false>(T2, ld2, R, r, prow2, colbuf, i0, c2base, zbank, G, C - 1,
+        update_tile<TR, VPT, false, NT>(T2, ld2, R, r, prow2, colbuf, i0, c2base, zbank, G, C - 1,
                                     next_col, next_rhs);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_pivot_fused: one whole pivot (Solve :107-142 + Pivot :193-211) in ONE launch, for tableaux
+// small enough to live in L2 / Infinity Cache, where the cost of a pivot is launch latency, not
+// bytes.  Out of place (Tin -> Tout, the two buffers alternate) so that no workgroup can overwrite
+// what another still has to read; therefore EVERY workgroup can afford to redo the selection
+// itself -- Z-row arg-min (:152-167), ratio test over the two strided columns (:169-191) -- from
+// the read-only input (a few KB out of L2), and then updates its own TR x 512 tile with the
+// normalised pivot row formed on the fly (:199, :208).  Workgroup (0,0) alone records the pivot.
+template <int TR>
+__global__ __launch_bounds__(256) void k_pivot_fused(const double* __restrict__ Tin,
+                                                     double* __restrict__ Tout, int ld, int R,
+                                                     int C, int32_t* __restrict__ basis,
+                                                     int32_t* __restrict__ log, PivotState* st) {
+    __shared__ double lds_v[16];
+    __shared__ int lds_i[16];
+    if (st->status != kRunning) return;
+    const int tid = threadIdx.x;
+    const int nt = blockDim.x;
+    const bool lead = (blockIdx.x == 0 && blockIdx.y == 0);
+
+    Cand c;  // FindEnteringVariable
+    c.v = 0.0;
+    c.i = -1;
+    for (int j = tid; j < C - 1; j += nt) {
+        const double v = Tin[j];
+        if (v < c.v) {
+            c.v = v;
+            c.i = j;
+        }
+    }
+    c = block_cand_min(c, lds_v, lds_i);
+    const int e = c.i;
+    if (e < 0) {
+        if (lead && tid == 0) st->status = LPR_OK_OPTIMAL;
+        return;
+    }
+    Cand q;  // FindLeavingVariable
+    q.v = DBL_MAX;
+    q.i = -1;
+    const int rhs = C - 1;
+    for (int i = 1 + tid; i < R; i += nt) {
+        const double a = Tin[(size_t)i * ld + e];
+        if (a > 1e-9) {
+            const double ratio = Tin[(size_t)i * ld + rhs] / a;
+            if (ratio >= 0 && ratio < q.v) {
+                q.v = ratio;
+                q.i = i;
+            }
+        }
+    }
+    q = block_cand_min(q, lds_v, lds_i);
+    const int r = q.i;
+    if (r < 0) {
+        if (lead && tid == 0) st->status = LPR_UNBOUNDED;
+        return;
+    }
+
+    const int ld2 = ld >> 1;
+    const int c2 = blockIdx.x * nt + tid;
+    const int i0 = blockIdx.y * TR;
+    if (c2 < ld2) {
+        const double p = Tin[(size_t)r * ld + e];
+        const double2* __restrict__ in2 = reinterpret_cast<const double2*>(Tin);
+        double2* __restrict__ out2 = reinterpret_cast<double2*>(Tout);
+        const double2 pv = in2[(size_t)r * ld2 + c2];
+        double2 pr;
+        pr.x = (2 * c2 < C) ? pv.x / p : 0.0;      // :199 true division
+        pr.y = (2 * c2 + 1 < C) ? pv.y / p : 0.0;
+        double2 x[TR];
+        double f[TR];
+#pragma unroll
+        for (int k = 0; k < TR; ++k) {
+            const int i = i0 + k;
+            if (i < R) {
+                x[k] = in2[(size_t)i * ld2 + c2];
+                f[k] = Tin[(size_t)i * ld + e];  // :206, wave-uniform
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < TR; ++k) {
+            const int i = i0 + k;
+            if (i < R) {
+                double2 o;
+                const double px = f[k] * pr.x;  // product rounded ...
+                const double py = f[k] * pr.y;
+                o.x = x[k].x - px;              // ... then the difference (:208)
+                o.y = x[k].y - py;
+                if (i == r) o = pr;
+                out2[(size_t)i * ld2 + c2] = o;
+            }
+        }
+    }
+    if (lead && tid == 0) {
+        const int64_t it = st->iter;
+        basis[r - 1] = e;  // :142
+        if (it < st->log_cap) {
+            log[2 * it] = r;
+            log[2 * it + 1] = e;
+        }
+        st->iter = it + 1;  // :138 (no other workgroup reads the counter)
+        st->cur_r = r;
+        st->cur_e = e;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -692,11 +820,11 @@ void launch_pivot_head(lpr_tableau* t) {
                        t->state, reinterpret_cast<ZPart*>(t->zparts), G);
 }
 
-template <int TR, int VPT>
+template <int TR, int VPT, int NT = 0>
 static void launch_update_t(lpr_tableau* t, int check_status, int serpentine, int dump_next) {
     const int ld2 = t->ld / 2;
     dim3 grid((ld2 + 256 * VPT - 1) / (256 * VPT), (t->rows + TR - 1) / TR);
-    hipLaunchKernelGGL((k_update<TR, VPT>), grid, dim3(256), 0, t->eng->stream, t->T, t->ld,
+    hipLaunchKernelGGL((k_update<TR, VPT, NT>), grid, dim3(256), 0, t->eng->stream, t->T, t->ld,
                        t->rows, t->cols, t->rowbuf, t->colbuf, t->next_col, t->next_rhs, t->state,
                        reinterpret_cast<const ZPart*>(t->zparts), head_groups(t), check_status,
                        serpentine, dump_next);
@@ -707,6 +835,13 @@ int num_update_variants() { return 11; }
 
 void launch_update(lpr_tableau* t, int variant, int check_status, int dump_next) {
     const int serp = (variant >> 8) & 1;
+    const int nt = (variant >> 9) & 3;  // tuning: non-temporal loads (bit 9) / stores (bit 10)
+    if (nt && (variant & 0xff) == 5) {
+        if (nt == 1) launch_update_t<32, 1, 1>(t, check_status, serp, dump_next);
+        else if (nt == 2) launch_update_t<32, 1, 2>(t, check_status, serp, dump_next);
+        else launch_update_t<32, 1, 3>(t, check_status, serp, dump_next);
+        return;
+    }
     switch (variant & 0xff) {
         default:
         case 0: launch_update_t<16, 1>(t, check_status, serp, dump_next); break;
@@ -720,6 +855,24 @@ void launch_update(lpr_tableau* t, int variant, int check_status, int dump_next)
         case 8: launch_update_t<4, 1>(t, check_status, serp, dump_next); break;
         case 9: launch_update_t<2, 1>(t, check_status, serp, dump_next); break;
         case 10: launch_update_t<1, 1>(t, check_status, serp, dump_next); break;
+    }
+}
+
+// one fused pivot, in -> out (both rows x ld)
+void launch_pivot_fused(lpr_tableau* t, const double* in, double* out) {
+    const int ld2 = t->ld / 2;
+    const int rows = t->rows;
+    // tallest row tile that still yields >= 256 workgroups
+    const int ct = (ld2 + 255) / 256;
+    int tr = 8;
+    while (tr > 1 && ct * ((rows + tr - 1) / tr) < 256) tr >>= 1;
+    dim3 grid(ct, (rows + tr - 1) / tr);
+    hipStream_t s = t->eng->stream;
+    switch (tr) {
+        case 8: hipLaunchKernelGGL((k_pivot_fused<8>), grid, dim3(256), 0, s, in, out, t->ld, rows, t->cols, t->basis, t->log, t->state); break;
+        case 4: hipLaunchKernelGGL((k_pivot_fused<4>), grid, dim3(256), 0, s, in, out, t->ld, rows, t->cols, t->basis, t->log, t->state); break;
+        case 2: hipLaunchKernelGGL((k_pivot_fused<2>), grid, dim3(256), 0, s, in, out, t->ld, rows, t->cols, t->basis, t->log, t->state); break;
+        default: hipLaunchKernelGGL((k_pivot_fused<1>), grid, dim3(256), 0, s, in, out, t->ld, rows, t->cols, t->basis, t->log, t->state); break;
     }
 }
 

@@ -260,3 +260,25 @@ def test_extreme_aspect_ratios(engine, oracle, m, n, seed):
     assert tab.basis().tolist() == basis.tolist()
     assert tab.read().tobytes() == T.tobytes()
     tab.destroy()
+
+
+@pytest.mark.parametrize("m,n,seed", [(40, 70, 1), (300, 500, 2), (513, 200, 3)])
+def test_fused_and_pipelined_paths_agree(engine, oracle, m, n, seed):
+    """Small tableaux take the single-launch k_pivot_fused path (ping-pong buffers); variant
+    0x7fff forces the two-kernel pipelined path, 0x7ffe the fused one.  Same bits either way,
+    including odd pivot counts (live tableau left in the second buffer) and resumed solves."""
+    from lpr_381_group_v22_amd import Tableau
+    T, basis = oracle.gen_dense_tableau(m, n, seed)
+    st, piv, log = oracle.primal_solve(T, basis, 301)
+    for variant in (0x7fff, 0x7ffe, 0):
+        tab = Tableau.synthetic(engine, m, n, seed)
+        r1 = tab.solve(max_pivots=7, variant=variant, batch=4)      # odd count, partial batches
+        r2 = tab.solve(max_pivots=294, variant=variant)
+        assert r1.pivots + r2.pivots == piv and r2.status == st
+        assert tab.pivot_log().tolist() == log.tolist()
+        assert tab.basis().tolist() == basis.tolist()
+        assert tab.read().tobytes() == T.tobytes(), hex(variant)
+        x, z = tab.extract_solution(n)
+        xr, zr = oracle.extract_solution(T, n)
+        assert x.tobytes() == xr.tobytes() and z == zr
+        tab.destroy()
