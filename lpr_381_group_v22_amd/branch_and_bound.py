@@ -187,6 +187,44 @@ def _is_integer(v: float) -> bool:  # BranchBoundSimplexSolver.cs:595-599
     return abs(r - _round_int(r)) <= 1e-6
 
 
+def _round_int_np(x: np.ndarray) -> np.ndarray:
+    """Vectorised Math.Round(double) (same IEEE operations as _round_int, element-wise)."""
+    with np.errstate(invalid="ignore", over="ignore"):
+        t = x + 0.5
+        f = np.floor(t)
+        f = np.where((f == t) & (np.fmod(t, 2.0) != 0), f - 1.0, f)
+        r = np.copysign(f, x)
+        whole = (np.abs(x) < 9.2e18) & (x == np.trunc(x))
+        r = np.where(whole | ~np.isfinite(x), x, r)
+    return r
+
+
+def _round4_np(x: np.ndarray) -> np.ndarray:
+    with np.errstate(invalid="ignore", over="ignore"):
+        return np.where(np.abs(x) < 1e16, _round_int_np(x * 10000.0) / 10000.0, x)
+
+
+def score_nodes(vals: np.ndarray):
+    """Vectorised IsInteger (:595-599) + CheckIntegerBasicVar (:829-847) for a (nodes x nvars)
+    array of decision values: returns (all_integer[nodes], branch_var[nodes] (-1: none),
+    branch_value[nodes])."""
+    vals = np.asarray(vals, dtype=np.float64)
+    if vals.ndim == 1:
+        vals = vals.reshape(1, -1)
+    if vals.shape[1] == 0:
+        k = vals.shape[0]
+        return np.ones(k, dtype=bool), -np.ones(k, dtype=np.int64), np.zeros(k)
+    r = _round4_np(vals)
+    with np.errstate(invalid="ignore"):
+        is_int = np.abs(r - _round_int_np(r)) <= 1e-6
+        dist = np.where(is_int, np.inf, np.abs((vals - np.floor(vals)) - 0.5))
+    var = np.argmin(dist, axis=1)  # first occurrence of the minimum == "strict <, first wins"
+    none = np.isinf(dist[np.arange(vals.shape[0]), var]) | np.isnan(dist).all(axis=1)
+    var = np.where(none, -1, var)
+    value = np.where(none, 0.0, vals[np.arange(vals.shape[0]), np.maximum(var, 0)])
+    return is_int.all(axis=1), var, value
+
+
 def choose_branch(vals: Sequence[float]) -> Tuple[int, float]:
     """CheckIntegerBasicVar :829-847: the non-integer value whose fraction is closest to 0.5
     (strict <, first wins).  Returns (-1, 0.0) when every value is integral."""
@@ -245,20 +283,22 @@ def solve_level_synchronous(evaluator, nvars: int, *, rank: int = 0, world: int 
         if frontier:
             ids = [nid for nid, _ in frontier]
             zs, vals = evaluator.node_info(ids)
-            for (nid, path), z, v in zip(frontier, zs, vals):
+            all_int, bvar, bval = score_nodes(vals)
+            for q, ((nid, path), z) in enumerate(zip(frontier, zs)):
                 if count_here:
                     processed += 1
                 if enable_pruning and global_bound > -math.inf and z <= global_bound:
                     continue  # ShouldPrunebranch :995-1001 against the all-reduced bound
-                if all(_is_integer(t) for t in v):  # UpdateOptimalSolution :943-981
-                    cand = (float(z), path, [float(t) for t in v])
+                if all_int[q]:  # UpdateOptimalSolution :943-981
+                    cand = (float(z), path, [float(t) for t in vals[q]])
                     if best_local is None or cand[0] > best_local[0] or \
                             (cand[0] == best_local[0] and _dfs_before(cand[1], best_local[1])):
                         best_local = cand
                         best_z = max(best_z, cand[0])
-                k, val = choose_branch(v)  # CreateBranches :859-890
+                k = int(bvar[q])  # CreateBranches :859-890
                 if k < 0:
                     continue
+                val = float(bval[q])
                 for side, bnd in ((0, math.floor(val)), (1, math.ceil(val))):
                     parents.append(nid)
                     var.append(k)

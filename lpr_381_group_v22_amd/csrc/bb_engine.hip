@@ -74,14 +74,25 @@ static int bb_alloc_buf(lpr_bb* b, double** out) {
         b->free_bufs.pop_back();
         return LPR_OK_OPTIMAL;
     }
+    // grow the pool by a slab of buffers at a time (hundreds of children per level: one
+    // hipMalloc each would cost more than solving them)
+    const size_t bytes = b->buf_elems * sizeof(double);
+    size_t per = ((size_t)128 << 20) / bytes;
+    if (per < 4) per = 4;
+    if (per > 512) per = 512;
     double* p = nullptr;
-    hipError_t err = hipMalloc(&p, b->buf_elems * sizeof(double));
+    hipError_t err = hipMalloc(&p, per * bytes);
     if (err != hipSuccess) {
-        set_error("B&B node buffer allocation (%zu bytes) failed: %s",
-                  b->buf_elems * sizeof(double), hipGetErrorString(err));
+        per = 1;
+        err = hipMalloc(&p, bytes);
+    }
+    if (err != hipSuccess) {
+        set_error("B&B node buffer allocation (%zu bytes) failed: %s", bytes,
+                  hipGetErrorString(err));
         return err == hipErrorOutOfMemory ? LPR_OUT_OF_MEMORY : LPR_DEVICE_ERROR;
     }
-    b->all_bufs.push_back(p);
+    b->all_bufs.push_back(p);  // slab base: what hipFree gets at destroy
+    for (size_t k = 1; k < per; ++k) b->free_bufs.push_back(p + k * b->buf_elems);
     *out = p;
     return LPR_OK_OPTIMAL;
 }
@@ -218,7 +229,7 @@ static int bb_expand(lpr_bb* b, int count, const int32_t* parent_ids, const int3
     bb_launch_add_constraint(b, count, rows_max, cols_max);
 
     // DoDualSimplex: pivot steps until every child has left the running states
-    const int poll = 4;
+    int poll = 4;  // pivot steps queued between polls of the running counter (grows to 32)
     int64_t guard = 0;
     for (;;) {
         // k_bb_select and k_bb_update always run as a pair: a select that starts a pivot sets
@@ -229,6 +240,7 @@ static int bb_expand(lpr_bb* b, int count, const int32_t* parent_ids, const int3
                                st));
         LPR_HIP(hipStreamSynchronize(st));
         if (*b->h_running <= 0) break;
+        if (poll < 32) poll *= 2;
         if (++guard > (1 << 16)) {
             // the reference has no pivot cap either (a cycling LP spins for ever in the C#);
             // the engine gives up instead of hanging the stream

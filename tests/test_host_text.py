@@ -84,3 +84,22 @@ def test_table_format_layout():
     assert lines[2] == "Table\tx1\tx2\tt1\tRHS"
     assert lines[3] == "Z\t-2.000\t-3.000\t0.000\t0.000\t"
     assert lines[4] == "1\t1.000\t2.000\t1.000\t10.000\t"
+
+
+def test_vectorised_node_scoring_equals_scalar_rules():
+    """score_nodes (numpy) == IsInteger / CheckIntegerBasicVar applied value by value."""
+    import numpy as np
+    from lpr_381_group_v22_amd import branch_and_bound as bb
+    rng = np.random.RandomState(0)
+    vals = np.round(rng.uniform(-3, 9, size=(200, 7)), 4)
+    vals[rng.rand(200, 7) < 0.5] = rng.randint(0, 3, size=(200, 7))[rng.rand(200, 7) < 0.5].mean()
+    vals[5] = [0, 1, 2, 1, 0, 3, 1]
+    vals[6] = [0.5, 1.5, 2.5, 0.25, 0.75, 0.50005, 0.49995]
+    vals[7, 0] = 1e17
+    all_int, var, value = bb.score_nodes(vals)
+    for q in range(vals.shape[0]):
+        k, v = bb.choose_branch(list(vals[q]))
+        assert var[q] == k and (k < 0 or value[q] == v), q
+        assert all_int[q] == all(bb._is_integer(t) for t in vals[q]), q
+    xs = np.concatenate([rng.uniform(-50, 50, 500), [0.00005, 2.5, 3.5, -2.5, 1e16, 0.49999999999999994]])
+    assert [bb._round4(float(x)) for x in xs] == bb._round4_np(xs).tolist()
