@@ -159,6 +159,34 @@ int lpr_pivot_log_read(lpr_tableau* t, int32_t* rows_out, int32_t* cols_out, int
  * launches, summed and average duration in milliseconds (HIP events on the engine stream). */
 int lpr_tableau_kernel_stats(lpr_tableau* t, int64_t* launches, double* total_ms, double* avg_ms);
 
+/* ------------------------------------- cutting-plane side path ("next" row f3)
+ * The reference's dual simplex / second primal simplex / Gomory step (dead code in its menu,
+ * Program.cs:417-428) on the same device tableau: row 0 = objectiveRow, rows 1.. = constraintRows.
+ * They differ from PrimalSimplexSolver by EPS-band selection rules and by leaving rows whose
+ * factor is within 1e-9 of zero untouched.  `print_steps` reproduces the C# quirk that `iter`
+ * (and with it max_iters) only advances when printSteps is set; hard_cap (<= 0: none) is an
+ * extra pivot limit with no C# counterpart.
+ *   lpr_dual_solve     DualSimplexSolver.Solve     Simplex/DualSimplex.cs:14-114
+ *                      status: OPTIMAL (true) / INFEASIBLE_BASIS (false, :72-76) / PIVOT_LIMIT
+ *   lpr_primal2_solve  PrimalSimplexSolver2.Solve  Simplex/PrimalSimplexSolver2.cs:46-97
+ *                      status: OPTIMAL (true) / UNBOUNDED (false, :63-68) / PIVOT_LIMIT
+ *   lpr_cutting_plane  CuttingPlaneSolver.CuttingPlaneSolution
+ *                      IntegerProgramming/CuttingPlaneSolver.cs:64-229 (recursion unrolled, at most
+ *                      max_cuts cuts; every cut appends one ROW, no slack column, :104-110).
+ *                      *exit_code: 0 optimal tableau displayed (:224), 1 all RHS integral (:87-91),
+ *                      2 no pivot column on the cut (:134-138), 3 pivot too small (:146-150),
+ *                      4 dual simplex failed (:191), 5 "step finished" (:228), 6 max_cuts reached,
+ *                      7 an InvalidOperationException escaped a solver.
+ *   lpr_cut_log_read   pivots of this path in order: triples (kind 0 dual / 1 primal2 / 2 cut,
+ *                      row in the C#'s own numbering, column). */
+int lpr_dual_solve(lpr_tableau* t, int max_iters, int print_steps, int64_t hard_cap,
+                   lpr_solve_result* res);
+int lpr_primal2_solve(lpr_tableau* t, int max_iters, int print_steps, int64_t hard_cap,
+                      lpr_solve_result* res);
+int lpr_cutting_plane(lpr_tableau* t, int max_cuts, int64_t hard_cap, int32_t* exit_code,
+                      int32_t* cuts);
+int lpr_cut_log_read(lpr_tableau* t, int32_t* triples, int64_t cap, int64_t* count);
+
 /* -------------------------------------------------- revised primal simplex */
 
 typedef struct lpr_revised lpr_revised;

@@ -117,6 +117,10 @@ SIGNATURES = {
     "lpr_basis_read": (C.c_int, [_P, _I32]),
     "lpr_pivot_log_read": (C.c_int, [_P, _I32, _I32, C.c_int64, _I64]),
     "lpr_tableau_kernel_stats": (C.c_int, [_P, _I64, _D, _D]),
+    "lpr_dual_solve": (C.c_int, [_P, C.c_int, C.c_int, C.c_int64, C.POINTER(SolveResult)]),
+    "lpr_primal2_solve": (C.c_int, [_P, C.c_int, C.c_int, C.c_int64, C.POINTER(SolveResult)]),
+    "lpr_cutting_plane": (C.c_int, [_P, C.c_int, C.c_int64, _I32, _I32]),
+    "lpr_cut_log_read": (C.c_int, [_P, _I32, C.c_int64, _I64]),
     "lpr_revised_create": (C.c_int, [_P, C.c_int, C.c_int, _D, _D, C.c_int, _D, C.c_int, _PP]),
     "lpr_revised_synthetic": (C.c_int, [_P, C.c_int, C.c_int, C.c_uint64, _PP]),
     "lpr_revised_destroy": (C.c_int, [_P]),

@@ -100,5 +100,6 @@ struct lpr_tableau {
     hipGraphExec_t graph = nullptr;
     int graph_batch = 0;
     int graph_variant = -1;
-    const double* graph_T = nullptr;  // T at capture time (the fused path alternates T / T2)
+    const double* graph_T = nullptr;
+    void* cut = nullptr;              // lpr_cut_ctx of the cutting-plane side path (cut_kernels.hip)  // T at capture time (the fused path alternates T / T2)
 };

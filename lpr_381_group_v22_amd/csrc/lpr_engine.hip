@@ -39,6 +39,10 @@ void launch_synthetic(lpr_tableau* t, int m, int n, uint64_t seed);
 void rev_orphan(lpr_revised* s);
 // bb_engine.hip
 void bb_orphan(lpr_bb* b);
+}  // namespace lpr
+// cut_kernels.hip
+void lpr_cut_release(lpr_tableau* t);
+namespace lpr {
 
 enum : int { kSelEnter = 1, kSelLeave = 2, kSelCommit = 4, kSelFull = 7 };
 constexpr int kTimeStride = 4;  // opts.time_kernels samples one update launch in four
@@ -103,6 +107,7 @@ static void release_device(lpr_tableau* t) {
     hipSetDevice(t->eng->device);
     if (t->eng->stream) hipStreamSynchronize(t->eng->stream);
     drop_graph(t);
+    lpr_cut_release(t);
     for (hipEvent_t ev : t->ev) hipEventDestroy(ev);
     t->ev.clear();
     hipFree(t->T);

@@ -175,6 +175,39 @@ class Tableau:
         k = cnt.value
         return np.stack([rows[:k], cols[:k]], axis=1)
 
+    # ---- cutting-plane side path (DualSimplex.cs, PrimalSimplexSolver2.cs, CuttingPlaneSolver.cs)
+    def dual_solve(self, max_iters: int = 10000, print_steps: bool = True,
+                   hard_cap: int = 0) -> N.SolveResult:
+        res = N.SolveResult()
+        N.check(N.lib.lpr_dual_solve(self._h, max_iters, 1 if print_steps else 0, hard_cap,
+                                     C.byref(res)), "lpr_dual_solve")
+        return res
+
+    def primal2_solve(self, max_iters: int = 10000, print_steps: bool = False,
+                      hard_cap: int = 0) -> N.SolveResult:
+        res = N.SolveResult()
+        N.check(N.lib.lpr_primal2_solve(self._h, max_iters, 1 if print_steps else 0, hard_cap,
+                                        C.byref(res)), "lpr_primal2_solve")
+        return res
+
+    def cutting_plane(self, max_cuts: int = 8, hard_cap: int = 0) -> Tuple[int, int]:
+        """Returns (exit code, cuts); the tableau grows by one row per cut."""
+        ex, cuts = C.c_int32(), C.c_int32()
+        N.check(N.lib.lpr_cutting_plane(self._h, max_cuts, hard_cap, C.byref(ex), C.byref(cuts)),
+                "lpr_cutting_plane")
+        r, c, ld = C.c_int(), C.c_int(), C.c_int()
+        N.check(N.lib.lpr_tableau_shape(self._h, C.byref(r), C.byref(c), C.byref(ld)),
+                "lpr_tableau_shape")
+        self.rows, self.cols, self.ld = r.value, c.value, ld.value
+        return ex.value, cuts.value
+
+    def cut_log(self, cap: int = 1 << 16):
+        buf = np.zeros(cap * 3, dtype=np.int32)
+        n = C.c_int64()
+        N.check(N.lib.lpr_cut_log_read(self._h, _i32ptr(buf), cap, C.byref(n)),
+                "lpr_cut_log_read")
+        return [tuple(v) for v in buf[: 3 * n.value].reshape(-1, 3).tolist()]
+
     def kernel_stats(self) -> Tuple[int, float, float]:
         n, tot, avg = C.c_int64(), C.c_double(), C.c_double()
         N.check(N.lib.lpr_tableau_kernel_stats(self._h, C.byref(n), C.byref(tot), C.byref(avg)),

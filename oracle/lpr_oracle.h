@@ -88,6 +88,17 @@ int orc_bb_add_constraint(const double* base, int rows, int cols, const double* 
 int orc_bb_dual_simplex(const double* start, int rows, int cols, double* out, int* npiv,
                         int32_t* piv_trace, int64_t piv_cap, int64_t* n_piv);
 
+/* ---- cutting-plane side path: Simplex/DualSimplex.cs, Simplex/PrimalSimplexSolver2.cs,
+ *      IntegerProgramming/CuttingPlaneSolver.cs (see oracle_cut.c).  T: row 0 = objective row.
+ *      Return codes of the two solvers: 0 true / 1 false (infeasible resp. unbounded) /
+ *      3 pivot too small (exception) / 5 iteration limit.  Log triples (kind, row, col). ---- */
+int orc_dual_solve(double* T, int R, int C, int max_iters, int print_steps, int64_t hard_cap,
+                   int32_t* log, int64_t log_cap, int64_t* n_log, int64_t* pivots);
+int orc_primal2_solve(double* T, int R, int C, int max_iters, int print_steps, int64_t hard_cap,
+                      int32_t* log, int64_t log_cap, int64_t* n_log, int64_t* pivots);
+int orc_cutting_plane(double* T, int* R_io, int R_cap, int C, int max_cuts, int64_t hard_cap,
+                      int32_t* log, int64_t log_cap, int64_t* n_log, int* cuts);
+
 #ifdef __cplusplus
 }
 #endif

@@ -85,6 +85,48 @@ class Oracle:
         lib.orc_bb_dual_simplex.restype = C.c_int
         lib.orc_bb_dual_simplex.argtypes = [_D, C.c_int, C.c_int, _D, _IP, _I32, C.c_int64, _I64]
 
+        for fn in (lib.orc_dual_solve, lib.orc_primal2_solve):
+            fn.restype = C.c_int
+            fn.argtypes = [_D, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, _I32, C.c_int64,
+                           _I64, _I64]
+        lib.orc_cutting_plane.restype = C.c_int
+        lib.orc_cutting_plane.argtypes = [_D, _IP, C.c_int, C.c_int, C.c_int, C.c_int64, _I32,
+                                          C.c_int64, _I64, _IP]
+
+    # ---- cutting-plane side path (T: row 0 = objective row; in place) ----
+    def _cut_solver(self, fn, T, max_iters, print_steps, hard_cap, log_cap):
+        assert T.flags["C_CONTIGUOUS"] and T.dtype == np.float64
+        log = np.zeros(log_cap * 3, dtype=np.int32)
+        nlog, piv = C.c_int64(), C.c_int64()
+        rc = fn(_dp(T), T.shape[0], T.shape[1], max_iters, 1 if print_steps else 0, hard_cap,
+                _ip(log), log_cap, C.byref(nlog), C.byref(piv))
+        q = min(nlog.value, log_cap)
+        return rc, piv.value, [tuple(v) for v in log[:3 * q].reshape(-1, 3).tolist()]
+
+    def dual_solve(self, T, max_iters=10000, print_steps=True, hard_cap=0, log_cap=1 << 14):
+        return self._cut_solver(self.lib.orc_dual_solve, T, max_iters, print_steps, hard_cap,
+                                log_cap)
+
+    def primal2_solve(self, T, max_iters=10000, print_steps=False, hard_cap=0, log_cap=1 << 14):
+        return self._cut_solver(self.lib.orc_primal2_solve, T, max_iters, print_steps, hard_cap,
+                                log_cap)
+
+    def cutting_plane(self, T, max_cuts=8, hard_cap=0, log_cap=1 << 14):
+        """Returns (exit code, cuts, final tableau (rows grown), log)."""
+        R, Cc = T.shape
+        buf = np.zeros((R + max_cuts, Cc))
+        buf[:R] = T
+        r_io = C.c_int(R)
+        log = np.zeros(log_cap * 3, dtype=np.int32)
+        nlog = C.c_int64()
+        cuts = C.c_int()
+        rc = self.lib.orc_cutting_plane(_dp(buf), C.byref(r_io), R + max_cuts, Cc, max_cuts,
+                                        hard_cap, _ip(log), log_cap, C.byref(nlog),
+                                        C.byref(cuts))
+        q = min(nlog.value, log_cap)
+        return rc, cuts.value, buf[:r_io.value].copy(), \
+            [tuple(v) for v in log[:3 * q].reshape(-1, 3).tolist()]
+
     # ---- branch & bound ----
     def round4(self, x):
         return self.lib.orc_round4(x)
