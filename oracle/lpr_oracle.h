@@ -99,6 +99,23 @@ int orc_primal2_solve(double* T, int R, int C, int max_iters, int print_steps, i
 int orc_cutting_plane(double* T, int* R_io, int R_cap, int C, int max_cuts, int64_t hard_cap,
                       int32_t* log, int64_t log_cap, int64_t* n_log, int* cuts);
 
+/* ---- sensitivity re-solve (SensitivityAnalysis/SensitivityAnalyzer.cs; see oracle_sens.c).
+ *      Return codes: 0 ok, 1 unbounded, 2 infeasible, 3 zero pivot, 5 iteration limit,
+ *      8 ChangeRHS rolled back, 9 IndexOutOfRange in AddNewConstraint, -1 invalid index. ---- */
+typedef struct orc_sens orc_sens;
+orc_sens* orc_sens_create(const double* finalTableau, int R, int C, const double* solution,
+                          int nsol, double z, const int32_t* basic, int nbasic);
+void orc_sens_destroy(orc_sens* s);
+void orc_sens_shape(const orc_sens* s, int* R, int* C, int* nsol, int* nbasic, double* z);
+void orc_sens_read(const orc_sens* s, double* T, int32_t* basic, double* sol);
+int orc_sens_resolve_all(orc_sens* s);
+int orc_sens_change_nonbasic_cbar(orc_sens* s, int index, double newCbar);
+int orc_sens_change_basic(orc_sens* s, int col, double delta);
+int orc_sens_change_rhs(orc_sens* s, int k, double newB);
+int orc_sens_change_nonbasic_column(orc_sens* s, int row, int col, double newVal);
+int orc_sens_add_activity(orc_sens* s, double cNew, const double* aNew);
+int orc_sens_add_constraint(orc_sens* s, const double* tech, int ntech, double rhs);
+
 #ifdef __cplusplus
 }
 #endif

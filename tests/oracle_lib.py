@@ -93,6 +93,33 @@ class Oracle:
         lib.orc_cutting_plane.argtypes = [_D, _IP, C.c_int, C.c_int, C.c_int, C.c_int64, _I32,
                                           C.c_int64, _I64, _IP]
 
+        lib.orc_sens_create.restype = C.c_void_p
+        lib.orc_sens_create.argtypes = [_D, C.c_int, C.c_int, _D, C.c_int, C.c_double, _I32,
+                                        C.c_int]
+        lib.orc_sens_destroy.restype = None
+        lib.orc_sens_destroy.argtypes = [C.c_void_p]
+        lib.orc_sens_shape.restype = None
+        lib.orc_sens_shape.argtypes = [C.c_void_p, _IP, _IP, _IP, _IP, _D]
+        lib.orc_sens_read.restype = None
+        lib.orc_sens_read.argtypes = [C.c_void_p, _D, _I32, _D]
+        lib.orc_sens_resolve_all.restype = C.c_int
+        lib.orc_sens_resolve_all.argtypes = [C.c_void_p]
+        lib.orc_sens_change_nonbasic_cbar.restype = C.c_int
+        lib.orc_sens_change_nonbasic_cbar.argtypes = [C.c_void_p, C.c_int, C.c_double]
+        lib.orc_sens_change_basic.restype = C.c_int
+        lib.orc_sens_change_basic.argtypes = [C.c_void_p, C.c_int, C.c_double]
+        lib.orc_sens_change_rhs.restype = C.c_int
+        lib.orc_sens_change_rhs.argtypes = [C.c_void_p, C.c_int, C.c_double]
+        lib.orc_sens_change_nonbasic_column.restype = C.c_int
+        lib.orc_sens_change_nonbasic_column.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double]
+        lib.orc_sens_add_activity.restype = C.c_int
+        lib.orc_sens_add_activity.argtypes = [C.c_void_p, C.c_double, _D]
+        lib.orc_sens_add_constraint.restype = C.c_int
+        lib.orc_sens_add_constraint.argtypes = [C.c_void_p, _D, C.c_int, C.c_double]
+
+    def sens(self, final_tableau, solution, z, basic):
+        return OracleSens(self.lib, final_tableau, solution, z, basic)
+
     # ---- cutting-plane side path (T: row 0 = objective row; in place) ----
     def _cut_solver(self, fn, T, max_iters, print_steps, hard_cap, log_cap):
         assert T.flags["C_CONTIGUOUS"] and T.dtype == np.float64
@@ -280,3 +307,54 @@ class Oracle:
         z = C.c_double()
         self.lib.orc_extract_solution(_dp(T), T.shape[0], T.shape[1], n, _dp(x), C.byref(z))
         return x[:n], z.value
+
+
+class OracleSens:
+    """Handle on an orc_sens (oracle/oracle_sens.c): the re-solve half of SensitivityAnalyzer."""
+
+    def __init__(self, lib, final_tableau, solution, z, basic):
+        self.lib = lib
+        T = np.ascontiguousarray(final_tableau, dtype=np.float64)
+        sol = np.ascontiguousarray(solution, dtype=np.float64)
+        b = np.ascontiguousarray(basic, dtype=np.int32)
+        self.h = lib.orc_sens_create(_dp(T), T.shape[0], T.shape[1], _dp(sol), sol.shape[0],
+                                     float(z), _ip(b), b.shape[0])
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.orc_sens_destroy(self.h)
+            self.h = None
+
+    def state(self):
+        R, Cc, ns, nb = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        z = C.c_double()
+        self.lib.orc_sens_shape(self.h, C.byref(R), C.byref(Cc), C.byref(ns), C.byref(nb),
+                                C.byref(z))
+        T = np.zeros((R.value, Cc.value))
+        basic = np.zeros(max(nb.value, 1), dtype=np.int32)
+        sol = np.zeros(max(ns.value, 1))
+        self.lib.orc_sens_read(self.h, _dp(T), _ip(basic), _dp(sol))
+        return dict(T=T, basic=basic[:nb.value].tolist(), sol=sol[:ns.value], z=z.value)
+
+    def resolve_all(self):
+        return self.lib.orc_sens_resolve_all(self.h)
+
+    def change_nonbasic_cbar(self, index, new):
+        return self.lib.orc_sens_change_nonbasic_cbar(self.h, index, float(new))
+
+    def change_basic(self, col, delta):
+        return self.lib.orc_sens_change_basic(self.h, col, float(delta))
+
+    def change_rhs(self, k, new_b):
+        return self.lib.orc_sens_change_rhs(self.h, k, float(new_b))
+
+    def change_nonbasic_column(self, row, col, new):
+        return self.lib.orc_sens_change_nonbasic_column(self.h, row, col, float(new))
+
+    def add_activity(self, c_new, a_new):
+        a = np.ascontiguousarray(a_new, dtype=np.float64)
+        return self.lib.orc_sens_add_activity(self.h, float(c_new), _dp(a))
+
+    def add_constraint(self, tech, rhs):
+        t = np.ascontiguousarray(tech, dtype=np.float64)
+        return self.lib.orc_sens_add_constraint(self.h, _dp(t), t.shape[0], float(rhs))
