@@ -304,6 +304,62 @@ int lpr_bb_expand(lpr_bb* b, int count, const int32_t* parent_ids, const int32_t
 int lpr_bb_release(lpr_bb* b, const int32_t* ids, int count);
 int lpr_bb_node_read(lpr_bb* b, int32_t id, double* out, int32_t* rows, int32_t* cols);
 
+/* ------------------------------------------------------------------------------------------
+ * Sensitivity re-solve ("next" row f4): SensitivityAnalysis/SensitivityAnalyzer.cs.
+ * The analyzer owns a device copy of the final tableau (the C# clones it, :24).  The console
+ * prompts of the C# become arguments; every edit reports an lpr_sens_outcome through *outcome
+ * (the function's own return value is an lpr_status: < 0 only for API / device failures).
+ * Range displays, shadow prices and the duality print-out are read-only arithmetic on a few rows
+ * and columns: the host mirror does them from lpr_sens_read_block / lpr_sens_column_fold. */
+typedef struct lpr_sens lpr_sens;
+
+enum lpr_sens_outcome {
+    LPR_SENS_OK = 0,                 /* re-solved; z / solution vector refreshed (:159-165)      */
+    LPR_SENS_UNBOUNDED = 1,          /* "Unbounded during re-optimization." :151                 */
+    LPR_SENS_INFEASIBLE = 2,         /* "Infeasible after RHS change (dual simplex)." :197       */
+    LPR_SENS_ZERO_PIVOT = 3,         /* "Zero pivot encountered." :101                           */
+    LPR_SENS_ITER_LIMIT = 5,         /* "Iteration limit in ReOptimize / dual simplex" :126 :183 */
+    LPR_SENS_ROLLED_BACK = 8,        /* ChangeRHS caught an exception and restored (:462-469)    */
+    LPR_SENS_INDEX_OUT_OF_RANGE = 9, /* AddNewConstraint: a row without a basic column (tech[-1]) */
+    LPR_SENS_INVALID_INDEX = -1      /* the C# prints "Invalid ..." and returns; nothing changed */
+};
+
+/* ctor :22-39 (basicVariables is rebuilt from the tableau by :35, so it is not an argument).
+ * final_tableau is rows x cols row-major with row 0 = Z row; cols >= rows. */
+int lpr_sens_create(lpr_engine* e, const double* final_tableau, int32_t rows, int32_t cols,
+                    const double* solution, int32_t nsol, double z, lpr_sens** out);
+/* Program.cs:147-151: primalSolver.GetFinalTableau() / SolutionVector / FinalZ handed over device
+ * to device from a solved primal tableau (n_decision = objective.Count). */
+int lpr_sens_create_from_tableau(lpr_tableau* t, int32_t n_decision, lpr_sens** out);
+int lpr_sens_destroy(lpr_sens* s);
+/* numRows, numCols, solutionVector.Count, basicVars.Count, CurrentZ :728, pivots of the last edit */
+int lpr_sens_shape(lpr_sens* s, int32_t* rows, int32_t* cols, int32_t* nsol, int32_t* nbasic,
+                   double* z, int64_t* last_pivots);
+/* CurrentTableau :727 (rows x cols, dense), basicVars, CurrentSolutionVector :729; any may be NULL */
+int lpr_sens_read(lpr_sens* s, double* tableau, int32_t* basic, double* solution);
+int lpr_sens_read_block(lpr_sens* s, int32_t row0, int32_t nrows, int32_t col0, int32_t ncols,
+                        double* out);
+int lpr_sens_basic_row(lpr_sens* s, int32_t col, int32_t* row);   /* GetBasicRow :69-77 */
+/* (kind 0 dual / 1 primal, leaveRow, enterCol) of every pivot since creation; *count = total */
+int lpr_sens_log_read(lpr_sens* s, int32_t* triples, int64_t cap, int64_t* count);
+/* out[j] = (init ? init[j] : 0) + sum_{i<nw, in order} w[i] * tableau[i+1, j], j < ncols; nw must
+ * be rows-1.  The order-faithful column sums of :636-645 and PerformDuality :690-694. */
+int lpr_sens_column_fold(lpr_sens* s, const double* w, int32_t nw, const double* init,
+                         int32_t ncols, double* out);
+int lpr_sens_resolve_all(lpr_sens* s, int32_t* outcome);                       /* :203-208 */
+/* ChangeNonBasicReducedCost :300-321 (index 0-based, new_cbar is the new Z-C entry) */
+int lpr_sens_change_nonbasic_cbar(lpr_sens* s, int32_t index, double new_cbar, int32_t* outcome);
+int lpr_sens_change_basic(lpr_sens* s, int32_t col, double delta, int32_t* outcome); /* :362-393 */
+/* ChangeRHS :427-470 (k = constraint 1..rows-1, new_b replaces the CURRENT tableau RHS) */
+int lpr_sens_change_rhs(lpr_sens* s, int32_t k, double new_b, int32_t* outcome);
+int lpr_sens_change_nonbasic_column(lpr_sens* s, int32_t row, int32_t col, double new_val,
+                                    int32_t* outcome);                          /* :502-531 */
+int lpr_sens_add_activity(lpr_sens* s, double c_new, const double* a_new, int32_t na,
+                          int32_t* outcome);                                    /* :534-584 */
+/* AddNewConstraintNonInteractive :609-659 (tech has cols-1 entries, <= row) */
+int lpr_sens_add_constraint(lpr_sens* s, const double* tech, int32_t ntech, double rhs,
+                            int32_t* outcome);
+
 #ifdef __cplusplus
 }
 #endif

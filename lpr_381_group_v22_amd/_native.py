@@ -32,6 +32,16 @@ STATUS_NAMES = {
 
 LPR_REL_LE, LPR_REL_GE, LPR_REL_EQ = 0, 1, 2
 
+# lpr_sens_outcome
+LPR_SENS_OK = 0
+LPR_SENS_UNBOUNDED = 1
+LPR_SENS_INFEASIBLE = 2
+LPR_SENS_ZERO_PIVOT = 3
+LPR_SENS_ITER_LIMIT = 5
+LPR_SENS_ROLLED_BACK = 8
+LPR_SENS_INDEX_OUT_OF_RANGE = 9
+LPR_SENS_INVALID_INDEX = -1
+
 
 class SolveOpts(C.Structure):
     _fields_ = [
@@ -142,6 +152,22 @@ SIGNATURES = {
     "lpr_bb_expand": (C.c_int, [_P, C.c_int, _I32, _I32, _D, _I32, _I32, _I32, _I32]),
     "lpr_bb_release": (C.c_int, [_P, _I32, C.c_int]),
     "lpr_bb_node_read": (C.c_int, [_P, C.c_int32, _D, _I32, _I32]),
+    "lpr_sens_create": (C.c_int, [_P, _D, C.c_int32, C.c_int32, _D, C.c_int32, C.c_double, _PP]),
+    "lpr_sens_create_from_tableau": (C.c_int, [_P, C.c_int32, _PP]),
+    "lpr_sens_destroy": (C.c_int, [_P]),
+    "lpr_sens_shape": (C.c_int, [_P, _I32, _I32, _I32, _I32, _D, _I64]),
+    "lpr_sens_read": (C.c_int, [_P, _D, _I32, _D]),
+    "lpr_sens_read_block": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _D]),
+    "lpr_sens_basic_row": (C.c_int, [_P, C.c_int32, _I32]),
+    "lpr_sens_log_read": (C.c_int, [_P, _I32, C.c_int64, _I64]),
+    "lpr_sens_column_fold": (C.c_int, [_P, _D, C.c_int32, _D, C.c_int32, _D]),
+    "lpr_sens_resolve_all": (C.c_int, [_P, _I32]),
+    "lpr_sens_change_nonbasic_cbar": (C.c_int, [_P, C.c_int32, C.c_double, _I32]),
+    "lpr_sens_change_basic": (C.c_int, [_P, C.c_int32, C.c_double, _I32]),
+    "lpr_sens_change_rhs": (C.c_int, [_P, C.c_int32, C.c_double, _I32]),
+    "lpr_sens_change_nonbasic_column": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_double, _I32]),
+    "lpr_sens_add_activity": (C.c_int, [_P, C.c_double, _D, C.c_int32, _I32]),
+    "lpr_sens_add_constraint": (C.c_int, [_P, _D, C.c_int32, C.c_double, _I32]),
 }
 
 

@@ -59,6 +59,7 @@ struct PivotState {
 struct lpr_tableau;
 struct lpr_revised;
 struct lpr_bb;
+struct lpr_sens;
 
 struct lpr_engine {
     int device = 0;
@@ -70,6 +71,7 @@ struct lpr_engine {
     std::vector<lpr_tableau*> live;
     std::vector<lpr_revised*> live_rev;
     std::vector<lpr_bb*> live_bb;
+    std::vector<lpr_sens*> live_sens;
 };
 
 struct lpr_tableau {

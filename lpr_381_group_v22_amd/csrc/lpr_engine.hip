@@ -39,6 +39,8 @@ void launch_synthetic(lpr_tableau* t, int m, int n, uint64_t seed);
 void rev_orphan(lpr_revised* s);
 // bb_engine.hip
 void bb_orphan(lpr_bb* b);
+// sens_engine.hip
+void sens_orphan(lpr_sens* s);
 }  // namespace lpr
 // cut_kernels.hip
 void lpr_cut_release(lpr_tableau* t);
@@ -354,6 +356,8 @@ int lpr_engine_close(lpr_engine* e) {
     e->live_rev.clear();
     for (lpr_bb* b : e->live_bb) bb_orphan(b);
     e->live_bb.clear();
+    for (lpr_sens* q : e->live_sens) sens_orphan(q);
+    e->live_sens.clear();
     if (e->stream) {
         hipStreamSynchronize(e->stream);
         hipStreamDestroy(e->stream);

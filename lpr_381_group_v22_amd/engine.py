@@ -300,3 +300,116 @@ class RevisedState:
         ms = C.c_double()
         N.check(N.lib.lpr_revised_binv_a(self._h, _dptr(out), C.byref(ms)), "lpr_revised_binv_a")
         return out, ms.value
+
+
+class SensState:
+    """Device-resident tableau of a SensitivityAnalyzer (lpr_sens_*).  Edits return the
+    lpr_sens_outcome of the re-solve."""
+
+    def __init__(self, engine: Engine, handle: C.c_void_p):
+        self.engine = engine
+        self._h = handle
+
+    @classmethod
+    def create(cls, engine: Engine, final_tableau: np.ndarray, solution: Sequence[float],
+               z: float) -> "SensState":
+        T = np.ascontiguousarray(final_tableau, dtype=np.float64)
+        sol = np.ascontiguousarray(solution, dtype=np.float64)
+        h = C.c_void_p()
+        N.check(N.lib.lpr_sens_create(engine._h, _dptr(T), T.shape[0], T.shape[1],
+                                      _dptr(sol) if sol.size else None, sol.shape[0], float(z),
+                                      C.byref(h)), "lpr_sens_create")
+        return cls(engine, h)
+
+    @classmethod
+    def from_tableau(cls, tableau: Tableau, n_decision: int) -> "SensState":
+        h = C.c_void_p()
+        N.check(N.lib.lpr_sens_create_from_tableau(tableau._h, n_decision, C.byref(h)),
+                "lpr_sens_create_from_tableau")
+        return cls(tableau.engine, h)
+
+    def destroy(self):
+        if self._h:
+            N.lib.lpr_sens_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+    def shape(self):
+        """(rows, cols, nsol, nbasic, z, pivots of the last edit)"""
+        r, c, ns, nb = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        z, p = C.c_double(), C.c_int64()
+        N.check(N.lib.lpr_sens_shape(self._h, C.byref(r), C.byref(c), C.byref(ns), C.byref(nb),
+                                     C.byref(z), C.byref(p)), "lpr_sens_shape")
+        return r.value, c.value, ns.value, nb.value, z.value, p.value
+
+    def read(self, tableau: bool = True):
+        """(tableau or None, basicVars, solutionVector)"""
+        r, c, ns, nb, _, _ = self.shape()
+        T = np.empty((r, c), dtype=np.float64) if tableau else None
+        basic = np.zeros(max(nb, 1), dtype=np.int32)
+        sol = np.zeros(max(ns, 1), dtype=np.float64)
+        N.check(N.lib.lpr_sens_read(self._h, _dptr(T), _i32ptr(basic), _dptr(sol)),
+                "lpr_sens_read")
+        return T, basic[:nb], sol[:ns]
+
+    def read_block(self, row0: int, nrows: int, col0: int, ncols: int) -> np.ndarray:
+        out = np.empty((nrows, ncols), dtype=np.float64)
+        N.check(N.lib.lpr_sens_read_block(self._h, row0, nrows, col0, ncols, _dptr(out)),
+                "lpr_sens_read_block")
+        return out
+
+    def basic_row(self, col: int) -> int:
+        r = C.c_int32()
+        N.check(N.lib.lpr_sens_basic_row(self._h, col, C.byref(r)), "lpr_sens_basic_row")
+        return r.value
+
+    def log(self):
+        cnt = C.c_int64()
+        N.check(N.lib.lpr_sens_log_read(self._h, None, 0, C.byref(cnt)), "lpr_sens_log_read")
+        n = cnt.value
+        buf = np.zeros(max(3 * n, 3), dtype=np.int32)
+        N.check(N.lib.lpr_sens_log_read(self._h, _i32ptr(buf), n, C.byref(cnt)),
+                "lpr_sens_log_read")
+        return [tuple(v) for v in buf[:3 * n].reshape(-1, 3).tolist()]
+
+    def column_fold(self, w: Sequence[float], init: Optional[Sequence[float]],
+                    ncols: int) -> np.ndarray:
+        ww = np.ascontiguousarray(w, dtype=np.float64)
+        ii = None if init is None else np.ascontiguousarray(init, dtype=np.float64)
+        out = np.zeros(max(ncols, 1), dtype=np.float64)
+        N.check(N.lib.lpr_sens_column_fold(self._h, _dptr(ww), ww.shape[0], _dptr(ii), ncols,
+                                           _dptr(out)), "lpr_sens_column_fold")
+        return out[:ncols]
+
+    def _edit(self, name: str, *args) -> int:
+        oc = C.c_int32()
+        N.check(getattr(N.lib, name)(self._h, *args, C.byref(oc)), name)
+        return oc.value
+
+    def resolve_all(self) -> int:
+        return self._edit("lpr_sens_resolve_all")
+
+    def change_nonbasic_cbar(self, index: int, new_cbar: float) -> int:
+        return self._edit("lpr_sens_change_nonbasic_cbar", index, float(new_cbar))
+
+    def change_basic(self, col: int, delta: float) -> int:
+        return self._edit("lpr_sens_change_basic", col, float(delta))
+
+    def change_rhs(self, k: int, new_b: float) -> int:
+        return self._edit("lpr_sens_change_rhs", k, float(new_b))
+
+    def change_nonbasic_column(self, row: int, col: int, new_val: float) -> int:
+        return self._edit("lpr_sens_change_nonbasic_column", row, col, float(new_val))
+
+    def add_activity(self, c_new: float, a_new: Sequence[float]) -> int:
+        a = np.ascontiguousarray(a_new, dtype=np.float64)
+        return self._edit("lpr_sens_add_activity", float(c_new), _dptr(a), a.shape[0])
+
+    def add_constraint(self, tech: Sequence[float], rhs: float) -> int:
+        t = np.ascontiguousarray(tech, dtype=np.float64)
+        return self._edit("lpr_sens_add_constraint", _dptr(t), t.shape[0], float(rhs))

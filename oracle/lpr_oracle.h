@@ -108,6 +108,8 @@ orc_sens* orc_sens_create(const double* finalTableau, int R, int C, const double
 void orc_sens_destroy(orc_sens* s);
 void orc_sens_shape(const orc_sens* s, int* R, int* C, int* nsol, int* nbasic, double* z);
 void orc_sens_read(const orc_sens* s, double* T, int32_t* basic, double* sol);
+/* (kind 0 dual / 1 primal, leaveRow, enterCol) of every pivot so far; returns the total count */
+int64_t orc_sens_log_read(const orc_sens* s, int32_t* triples, int64_t cap);
 int orc_sens_resolve_all(orc_sens* s);
 int orc_sens_change_nonbasic_cbar(orc_sens* s, int index, double newCbar);
 int orc_sens_change_basic(orc_sens* s, int col, double delta);

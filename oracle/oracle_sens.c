@@ -33,6 +33,8 @@ typedef struct orc_sens {
     int nsol;     /* solutionVector.Count */
     double* sol;
     double z;
+    int32_t* log; /* (kind 0 dual / 1 primal, leaveRow, enterCol) of every pivot performed */
+    int64_t nlog, logcap;
 } orc_sens;
 
 #define TT(s, i, j) ((s)->T[(size_t)(i) * (s)->C + (j)])
@@ -76,9 +78,17 @@ static int is_optimal(const orc_sens* s) { /* :86-96 */
     return 1;
 }
 
-static int pivot(orc_sens* s, int enterCol, int leaveRow) { /* :98-119 */
+static int pivot(orc_sens* s, int enterCol, int leaveRow, int kind) { /* :98-119 */
     double piv = TT(s, leaveRow, enterCol);
     if (fabs(piv) < EPS) return 3;
+    if (s->nlog == s->logcap) {
+        s->logcap = s->logcap ? 2 * s->logcap : 64;
+        s->log = (int32_t*)realloc(s->log, sizeof(int32_t) * 3 * (size_t)s->logcap);
+    }
+    s->log[3 * s->nlog] = kind;
+    s->log[3 * s->nlog + 1] = leaveRow;
+    s->log[3 * s->nlog + 2] = enterCol;
+    s->nlog++;
     for (int j = 0; j < s->C; j++) TT(s, leaveRow, j) /= piv;
     for (int i = 0; i < s->R; i++) {
         if (i == leaveRow) continue;
@@ -116,7 +126,7 @@ static int reoptimize(orc_sens* s, int maxIter) { /* :121-166 */
             }
         }
         if (leave == -1) return 1;
-        int rc2 = pivot(s, enter, leave);
+        int rc2 = pivot(s, enter, leave, 1);
         if (rc2) return rc2;
     }
     s->z = TT(s, 0, s->C - 1);
@@ -150,7 +160,7 @@ static int dual_if_needed(orc_sens* s, int maxIter) { /* :168-201 */
             }
         }
         if (enter == -1) return 2;
-        int rc = pivot(s, enter, leave);
+        int rc = pivot(s, enter, leave, 0);
         if (rc) return rc;
     }
     return 0;
@@ -195,6 +205,7 @@ void orc_sens_destroy(orc_sens* s) {
     free(s->T);
     free(s->basic);
     free(s->sol);
+    free(s->log);
     free(s);
 }
 
@@ -210,6 +221,12 @@ void orc_sens_read(const orc_sens* s, double* T, int32_t* basic, double* sol) {
     if (T) memcpy(T, s->T, sizeof(double) * (size_t)s->R * s->C);
     if (basic) for (int i = 0; i < s->nb; i++) basic[i] = s->basic[i];
     if (sol) memcpy(sol, s->sol, sizeof(double) * s->nsol);
+}
+
+int64_t orc_sens_log_read(const orc_sens* s, int32_t* triples, int64_t cap) {
+    int64_t k = s->nlog < cap ? s->nlog : cap;
+    if (triples && k > 0) memcpy(triples, s->log, sizeof(int32_t) * 3 * (size_t)k);
+    return s->nlog;
 }
 
 int orc_sens_resolve_all(orc_sens* s) { return resolve_all(s); }

@@ -102,6 +102,8 @@ class Oracle:
         lib.orc_sens_shape.argtypes = [C.c_void_p, _IP, _IP, _IP, _IP, _D]
         lib.orc_sens_read.restype = None
         lib.orc_sens_read.argtypes = [C.c_void_p, _D, _I32, _D]
+        lib.orc_sens_log_read.restype = C.c_int64
+        lib.orc_sens_log_read.argtypes = [C.c_void_p, _I32, C.c_int64]
         lib.orc_sens_resolve_all.restype = C.c_int
         lib.orc_sens_resolve_all.argtypes = [C.c_void_p]
         lib.orc_sens_change_nonbasic_cbar.restype = C.c_int
@@ -335,6 +337,12 @@ class OracleSens:
         sol = np.zeros(max(ns.value, 1))
         self.lib.orc_sens_read(self.h, _dp(T), _ip(basic), _dp(sol))
         return dict(T=T, basic=basic[:nb.value].tolist(), sol=sol[:ns.value], z=z.value)
+
+    def log(self):
+        n = self.lib.orc_sens_log_read(self.h, None, 0)
+        buf = np.zeros(max(3 * n, 3), dtype=np.int32)
+        self.lib.orc_sens_log_read(self.h, _ip(buf), n)
+        return [tuple(v) for v in buf[:3 * n].reshape(-1, 3).tolist()]
 
     def resolve_all(self):
         return self.lib.orc_sens_resolve_all(self.h)

@@ -31,6 +31,7 @@ class PySens:
         self.z = z
         self.basic = list(basic)
         self.t[0][-1] = z
+        self.log = []
         self._rebuild()
 
     @property
@@ -63,11 +64,12 @@ class PySens:
         bs = set(self.basic)
         return all(j in bs or self.t[0][j] >= -EPS for j in range(self.C - 1))
 
-    def _pivot(self, enter, leave):  # :98-119
+    def _pivot(self, enter, leave, kind):  # :98-119
         t = self.t
         piv = t[leave][enter]
         if abs(piv) < EPS:
             raise ZeroPivot()
+        self.log.append((kind, leave, enter))
         for j in range(self.C):
             t[leave][j] = t[leave][j] / piv
         for i in range(self.R):
@@ -104,7 +106,7 @@ class PySens:
                         best, leave = ratio, i
             if leave == -1:
                 raise Unbounded()
-            self._pivot(enter, leave)
+            self._pivot(enter, leave, 1)
         self.z = self.t[0][-1]
         self.sol = []
         for j in range(self.C - 1):
@@ -133,7 +135,7 @@ class PySens:
                         best, enter = ratio, j
             if enter == -1:
                 raise Infeasible()
-            self._pivot(enter, leave)
+            self._pivot(enter, leave, 0)
 
     def resolve_all(self):  # :203-208
         self._rebuild()

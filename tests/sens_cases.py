@@ -45,6 +45,8 @@ def scripts(oracle):
             ("add_constraint", (None, 1.0)),                         # tech filled in by the test
             ("change_nonbasic_cbar", (10 ** 6, 1.0)),                # invalid index
             ("change_rhs", (1, 0.0)),
+            ("add_constraint_infeasible", ()),                       # code 2, state left mid-way
+            ("add_activity_unbounded", ()),                          # code 1
         ]
         out.append((f"lp_{m}x{n}_s{seed}", base, ops))
     return out
@@ -56,3 +58,15 @@ def make_tech(width: int, seed: int):
     k = max(1, width // 3)
     t[:k] = rng.randint(1, 4, size=k)
     return t.tolist()
+
+
+def materialize(op, args, T, k):
+    """Fill in the arguments that depend on the analyzer's current shape."""
+    R, C = T.shape
+    if op == "add_constraint":
+        return op, (make_tech(C - 1, 7 + k), args[1])
+    if op == "add_constraint_infeasible":       # sum of all columns <= -1 with x >= 0
+        return "add_constraint", ([1.0] * (C - 1), -1.0)
+    if op == "add_activity_unbounded":          # profitable activity that uses nothing
+        return "add_activity", (50.0, [-1.0] * (R - 1))
+    return op, args

@@ -14,9 +14,7 @@ def test_edit_scripts(oracle):
         st = o.state()
         assert np.array(p.t).tobytes() == st["T"].tobytes() and p.basic == st["basic"], name
         for k, (op, args) in enumerate(ops):
-            if op == "add_constraint":
-                width = o.state()["T"].shape[1] - 1
-                args = (sens_cases.make_tech(width, 7 + k), args[1])
+            op, args = sens_cases.materialize(op, args, o.state()["T"], k)
             rc = getattr(o, op)(*args)
             prc = rp.run(getattr(p, op), *args)
             prc = 0 if prc is None else prc
@@ -26,8 +24,9 @@ def test_edit_scripts(oracle):
             assert p.basic == st["basic"], (name, k, op)
             assert np.array(p.sol).tobytes() == st["sol"].tobytes(), (name, k, op)
             assert p.z == st["z"], (name, k, op)
+            assert p.log == o.log(), (name, k, op)
             codes.add(rc)
-    assert 0 in codes and -1 in codes and len(codes) >= 3, codes
+    assert {0, -1, 8} <= codes and (1 in codes or 2 in codes), codes
 
 
 def test_resolve_keeps_an_optimal_tableau_unchanged(oracle):
