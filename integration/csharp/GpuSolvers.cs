@@ -163,3 +163,88 @@ namespace LPR_381_Group_V22.IntegerProgramming
         }
     }
 }
+
+namespace LPR_381_Group_V22.SensitivityAnalysis
+{
+    using LPR_381_Group_V22.Simplex;
+
+    /// <summary>
+    /// The numeric half of SensitivityAnalyzer (SensitivityAnalyzer.cs) on the device.  The reference class keeps its
+    /// prompts / Console output and replaces its double[,] tableau + Pivot / ReOptimize / DualSimplexIfNeeded /
+    /// RebuildBasicsFromTableau by calls on this handle.  Uncompiled here (no .NET toolchain in the build image).
+    /// </summary>
+    internal sealed class GpuSensitivity : IDisposable
+    {
+        private IntPtr h;
+
+        // Program.cs:147-151 -- the solved tableau is copied device to device
+        internal GpuSensitivity(PrimalSimplexSolver primal, int numDecisionVariables)
+        {
+            NativeMethods.ThrowIfError(NativeMethods.lpr_sens_create_from_tableau(primal.Tableau, numDecisionVariables, out h), "lpr_sens_create_from_tableau");
+        }
+
+        // SensitivityAnalyzer(double[,], List<double>, double, List<int>) :22-39 (basicVariables is rebuilt by :35)
+        internal GpuSensitivity(double[,] finalTableau, List<double> solution, double zValue)
+        {
+            NativeMethods.ThrowIfError(NativeMethods.lpr_sens_create(Engine.Handle, finalTableau, finalTableau.GetLength(0), finalTableau.GetLength(1),
+                solution.ToArray(), solution.Count, zValue, out h), "lpr_sens_create");
+        }
+
+        private static void Throw(int outcome)
+        {
+            switch (outcome)
+            {
+                case 1: throw new InvalidOperationException("Unbounded during re-optimization.");            // :151
+                case 2: throw new InvalidOperationException("Infeasible after RHS change (dual simplex).");  // :197
+                case 3: throw new InvalidOperationException("Zero pivot encountered.");                      // :101
+                case 5: throw new InvalidOperationException("Re-optimization exceeded iteration limit.");    // :126 / :183
+                case 9: throw new IndexOutOfRangeException();                                                // tech[basicVars[pos]] with -1, :642
+            }
+        }
+
+        /// <returns>false when the C# would have printed "Invalid ..." and returned</returns>
+        internal bool ChangeNonBasicReducedCost(int index, double newCbar)
+        { NativeMethods.ThrowIfError(NativeMethods.lpr_sens_change_nonbasic_cbar(h, index, newCbar, out int oc), "lpr_sens_change_nonbasic_cbar"); Throw(oc); return oc == 0; }
+        internal bool ChangeBasic(int col, double delta)
+        { NativeMethods.ThrowIfError(NativeMethods.lpr_sens_change_basic(h, col, delta, out int oc), "lpr_sens_change_basic"); Throw(oc); return oc == 0; }
+        /// <returns>0 re-solved, 8 rolled back (the caller prints the C#'s message :467-468), -1 invalid index</returns>
+        internal int ChangeRHS(int k, double newB)
+        { NativeMethods.ThrowIfError(NativeMethods.lpr_sens_change_rhs(h, k, newB, out int oc), "lpr_sens_change_rhs"); return oc; }
+        internal bool ChangeNonBasicColumn(int row, int col, double newVal)
+        { NativeMethods.ThrowIfError(NativeMethods.lpr_sens_change_nonbasic_column(h, row, col, newVal, out int oc), "lpr_sens_change_nonbasic_column"); Throw(oc); return oc == 0; }
+        internal void AddNewActivity(double cNew, double[] aNew)
+        { NativeMethods.ThrowIfError(NativeMethods.lpr_sens_add_activity(h, cNew, aNew, aNew.Length, out int oc), "lpr_sens_add_activity"); Throw(oc); }
+        internal void AddNewConstraint(double[] tech, double rhs)
+        { NativeMethods.ThrowIfError(NativeMethods.lpr_sens_add_constraint(h, tech, tech.Length, rhs, out int oc), "lpr_sens_add_constraint"); Throw(oc); }
+
+        internal int GetBasicRow(int col) { NativeMethods.ThrowIfError(NativeMethods.lpr_sens_basic_row(h, col, out int r), "lpr_sens_basic_row"); return r; }   // :69-77
+
+        internal double[,] CurrentTableau   // :727
+        {
+            get
+            {
+                NativeMethods.lpr_sens_shape(h, out int R, out int C, out _, out _, out _, out _);
+                var t = new double[R, C];
+                NativeMethods.ThrowIfError(NativeMethods.lpr_sens_read(h, t, null, null), "lpr_sens_read");
+                return t;
+            }
+        }
+        internal double CurrentZ { get { NativeMethods.lpr_sens_shape(h, out _, out _, out _, out _, out double z, out _); return z; } }   // :728
+        internal List<double> CurrentSolutionVector   // :729
+        {
+            get
+            {
+                NativeMethods.lpr_sens_shape(h, out _, out _, out int ns, out _, out _, out _);
+                var x = new double[Math.Max(1, ns)];
+                NativeMethods.ThrowIfError(NativeMethods.lpr_sens_read(h, null, null, x), "lpr_sens_read");
+                return x.Take(ns).ToList();
+            }
+        }
+        internal double[] Row(int i) { NativeMethods.lpr_sens_shape(h, out _, out int C, out _, out _, out _, out _); var r = new double[C]; NativeMethods.ThrowIfError(NativeMethods.lpr_sens_read_block(h, i, 1, 0, C, r), "lpr_sens_read_block"); return r; }
+        internal double[] Column(int j) { NativeMethods.lpr_sens_shape(h, out int R, out _, out _, out _, out _, out _); var c = new double[R]; NativeMethods.ThrowIfError(NativeMethods.lpr_sens_read_block(h, 0, R, j, 1, c), "lpr_sens_read_block"); return c; }
+        // A-tilde^T y of RecoverObjectiveC / PerformDuality (:236-245, :690-694), summed in the C#'s order on the device
+        internal double[] ATy(double[] y, int n) { var o = new double[Math.Max(1, n)]; NativeMethods.ThrowIfError(NativeMethods.lpr_sens_column_fold(h, y, y.Length, null, n, o), "lpr_sens_column_fold"); return o; }
+
+        public void Dispose() { if (h != IntPtr.Zero) { NativeMethods.lpr_sens_destroy(h); h = IntPtr.Zero; } }
+    }
+}

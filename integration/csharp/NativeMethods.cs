@@ -90,6 +90,24 @@ namespace LPR_381_Group_V22.Native
         [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_bb_run(IntPtr bb, ref LprBbOpts opts, double[] x, out LprBbResult res);
         [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_bb_destroy(IntPtr bb);
 
+        // ---- SensitivityAnalyzer (SensitivityAnalysis/SensitivityAnalyzer.cs); outcome = lpr_sens_outcome ----
+        [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_sens_create(IntPtr engine, double[,] finalTableau, int rows, int cols, double[] solution, int nsol, double z, out IntPtr sens);
+        [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_sens_create_from_tableau(IntPtr tableau, int nDecision, out IntPtr sens);
+        [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_sens_destroy(IntPtr sens);
+        [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_sens_shape(IntPtr sens, out int rows, out int cols, out int nsol, out int nbasic, out double z, out long lastPivots);
+        [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_sens_read(IntPtr sens, double[,] tableau, int[] basic, double[] solution);
+        [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_sens_read_block(IntPtr sens, int row0, int nrows, int col0, int ncols, double[] block);
+        [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_sens_basic_row(IntPtr sens, int col, out int row);
+        [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_sens_log_read(IntPtr sens, int[] triples, long cap, out long count);
+        [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_sens_column_fold(IntPtr sens, double[] w, int nw, double[] init, int ncols, double[] result);
+        [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_sens_resolve_all(IntPtr sens, out int outcome);
+        [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_sens_change_nonbasic_cbar(IntPtr sens, int index, double newCbar, out int outcome);
+        [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_sens_change_basic(IntPtr sens, int col, double delta, out int outcome);
+        [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_sens_change_rhs(IntPtr sens, int k, double newB, out int outcome);
+        [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_sens_change_nonbasic_column(IntPtr sens, int row, int col, double newVal, out int outcome);
+        [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_sens_add_activity(IntPtr sens, double cNew, double[] aNew, int na, out int outcome);
+        [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_sens_add_constraint(IntPtr sens, double[] tech, int ntech, double rhs, out int outcome);
+
         internal static string LastError() => Marshal.PtrToStringAnsi(lpr_last_error()) ?? "";
 
         internal static void ThrowIfError(int status, string where)
