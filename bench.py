@@ -14,6 +14,7 @@
     replica (seed = rank): the path shards by independent sub-problems, no data-path collective.
 --workload revised (BASELINE configs[2]): revised-simplex iterations/s at the same size and the
     fp64-MFMA B^-1*A product (roofline bound "mfma").
+--workload sens (row f4): ChangeRHS edits re-solved by the dual simplex on the optimal tableau.
 --workload bb (BASELINE configs[3]): level-synchronous Branch & Bound, sub-trees sharded over the
     ranks, ONE RCCL all-reduce(MAX) of the incumbent per level; value = sub-problem pivots/s.
 """
@@ -318,12 +319,78 @@ def run_bb(args, D: Dist):
     return out
 
 
+# ------------------------------------------------------------------------------------ sens
+def run_sens(args, D: Dist):
+    """Sensitivity re-solve (row f4): the LP is solved on the device, handed to the analyzer HBM to
+    HBM, then every step is one ChangeRHS edit that tightens a constraint and is re-solved by
+    DualSimplexIfNeeded + ReOptimize.  value = re-solve pivots per second over the timed edits."""
+    import lpr_381_group_v22_amd as pkg
+    from lpr_381_group_v22_amd.engine import SensState
+    m, n, K, W = args.m, args.n, args.steps, args.warmup
+    R, C = m + 1, n + m + 1
+    bytes_per_pivot = 2 * 8 * R * C
+    eng = pkg.Engine(D.local_rank)
+    tab = pkg.Tableau.synthetic(eng, m, n, D.rank)
+    t0 = time.perf_counter()
+    res = tab.solve()
+    solve_s = time.perf_counter() - t0
+    if res.status != 0:
+        raise SystemExit(f"primal solve ended with status {res.status}")
+    sens = SensState.from_tableau(tab, n)
+    tab.destroy()
+
+    def edit(step):
+        k = 1 + (step * 997) % m
+        cur = float(sens.read_block(k, 1, C - 1, 1)[0, 0])
+        oc = sens.change_rhs(k, cur - 0.05 * abs(cur) - 1.0)
+        return oc, sens.shape()[5]
+
+    for w in range(W):
+        edit(w)
+    D.barrier(eng)
+    t0 = time.perf_counter()
+    piv = rolled = 0
+    for k in range(K):
+        oc, p = edit(W + k)
+        piv += p
+        rolled += 1 if oc == 8 else 0
+    D.barrier(eng)
+    dt = time.perf_counter() - t0
+    dt_max = D.max(dt)
+    piv_all = D.sum(float(piv))
+    out = None
+    if D.rank == 0:
+        achieved = piv * bytes_per_pivot / dt / 1e9
+        out = {
+            "metric": "sensitivity re-solve pivots/sec (ChangeRHS edits on the optimal tableau)",
+            "value": round(piv_all / dt_max, 2), "unit": "pivots/s", "n_gpus": D.world,
+            "steps": K, "warmup": W, "ms_per_step": round(dt_max * 1e3 / K, 6),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"dense random LP m={m} n={n} fp64 solved on the device "
+                                   f"({res.pivots} pivots, {solve_s:.2f} s), then {K} ChangeRHS "
+                                   f"edits re-solved by dual simplex on the {R}x{C} tableau",
+                       "m": m, "n": n, "edits": K, "pivots": piv, "rolled_back": rolled,
+                       "parallelism": f"replica{D.world}"},
+            "roofline": {"bound": "hbm", "kernel": "k_sens_update (pivot with |f|<EPS row skip)",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                         "note": "end-to-end lower bound: bytes of the pivots / wall time of the "
+                                 "edits (snapshot copy, selection kernels and host polls included)",
+                         "traffic": None},
+            "cpu_baseline": None,
+        }
+    sens.destroy()
+    eng.close()
+    return out
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=512)
     ap.add_argument("--warmup", type=int, default=64)
-    ap.add_argument("--workload", choices=["primal", "revised", "bb"], default="primal")
+    ap.add_argument("--workload", choices=["primal", "revised", "bb", "sens"], default="primal")
     ap.add_argument("--m", type=int, default=4096)
     ap.add_argument("--n", type=int, default=8192)
     ap.add_argument("--variant", type=int, default=0, help="rank-1 update kernel variant (0=auto)")
@@ -336,7 +403,8 @@ def main() -> int:
     ap.add_argument("--bb-levels", type=int, default=9)
     args = ap.parse_args()
     D = Dist(args)
-    out = {"primal": run_primal, "revised": run_revised, "bb": run_bb}[args.workload](args, D)
+    out = {"primal": run_primal, "revised": run_revised, "bb": run_bb,
+           "sens": run_sens}[args.workload](args, D)
     D.finish()
     if out is not None:
         print(json.dumps(out), flush=True)

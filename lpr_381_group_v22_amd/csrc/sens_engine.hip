@@ -24,6 +24,9 @@ struct lpr_sens {
     double* sol = nullptr;      // ld: solutionVector after a successful ReOptimize
     double* fold_w = nullptr;   // R: weights of a column fold
     double* fold_io = nullptr;  // ld: init / result of a column fold, also a staged new column
+    double* rhsd = nullptr;     // R: dense copy of the RHS column during a run
+    double* snapT = nullptr;    // ChangeRHS snapshot of T (lazy, kept until the shape changes)
+    int32_t* snapI = nullptr;   // ... of basic + bcount
     int32_t* basic = nullptr;   // R-1 (padded): basicVars
     int32_t* bcount = nullptr;  // ld: how many positions of basicVars hold column j
     int32_t* cnt = nullptr;     // ld: rows 1.. with |T[i][j]| > EPS
@@ -52,6 +55,8 @@ struct SensState {
     int32_t pr, pc;      // pivot of the pending update
     int32_t iter_dual;   // the C#'s `iter` of each loop
     int32_t iter_primal;
+    int32_t sweep;       // parity of the update sweep direction
+    int32_t pad;
     int64_t done;        // pivots of this run
     int64_t log_n, log_cap;
 };
@@ -161,14 +166,159 @@ __global__ __launch_bounds__(1024) void k_sens_basic_row(const double* __restric
 }
 
 // ---- one loop head of DualSimplexIfNeeded (:171-200) or ReOptimize (:124-157) --------------
+// The C#'s selections are sequential folds "take idx when val(idx) < best - EPS" over ascending
+// idx (NaN = not a candidate).  sens_fold replays one exactly and returns the last index taken
+// (-1: none).  Two facts make it cheap:
+//  (1) a take is always a strict prefix minimum of the sequence: everything before it was either
+//      taken (>= the current best) or skipped (>= its best - EPS >= the current best - EPS), and
+//      the take is below best - EPS.  So only the left-to-right minima -- about ln(n) of them on
+//      unordered data -- can ever be taken; they are found with one block-wide prefix-min scan
+//      (each thread owns a contiguous chunk, values stay in registers).
+//  (2) the sequential loop is then replayed over those few flagged candidates by the next-take
+//      search: every round finds the FIRST flagged index after the last take with
+//      val < best - EPS (a block-wide min), which is what the C# loop takes next.  Waves without a
+//      flagged candidate skip the scan; the reductions use ballots / readlanes, not the LDS pipe.
+// lds_i / lds_v: 32 entries each (two banks of one slot per wave, alternating per round).
+__device__ __forceinline__ double sens_readlane_f64(double x, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
+    return __hiloint2double(hi, lo);
+}
+
+template <int K, class F>
+__device__ __forceinline__ int sens_fold(int lo, int hi, double best, F val, int* lds_i,
+                                         double* lds_v) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int lane = tid & (kWave - 1), wave = tid / kWave, nw = nt / kWave;
+    const int n = hi - lo;
+    const int c = (n + nt - 1) / nt;  // candidates per thread, contiguous
+    const bool cached = c <= K;
+    const int base = lo + tid * c;
+    double v[K];
+    unsigned flags = 0;  // bit k: candidate base + k can still be taken
+    __syncthreads();     // lds_i / lds_v may still be read by a previous fold
+    if (cached) {
+        double lmin = INFINITY;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int idx = base + k;
+            v[k] = (k < c && idx < hi) ? val(idx) : NAN;
+            if (v[k] < lmin) {  // strict prefix minimum within the chunk
+                flags |= 1u << k;
+                lmin = v[k];
+            }
+        }
+        // exclusive prefix minimum of the chunk minima over the block
+        double inc = lmin;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            const double o = __shfl_up(inc, off, kWave);
+            if (lane >= off && o < inc) inc = o;
+        }
+        double exc = __shfl_up(inc, 1, kWave);
+        if (lane == 0) exc = INFINITY;
+        if (lane == kWave - 1) lds_v[wave] = inc;
+        __syncthreads();
+        const double wv = (lane < nw) ? lds_v[lane] : INFINITY;
+        for (int w = 0; w < wave; ++w) {
+            const double x = sens_readlane_f64(wv, w);
+            if (x < exc) exc = x;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            if (((flags >> k) & 1u) && !(v[k] < exc)) flags &= ~(1u << k);
+    }
+    int cur = -1;
+    for (int round = 0;; ++round) {
+        int first = INT_MAX;
+        double fv = 0.0;
+        if (cached) {
+            if (__ballot(flags != 0u) != 0ull) {
+                int myfirst = INT_MAX;
+                double myv = 0.0;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    if ((flags >> k) & 1u) {
+                        const int idx = base + k;
+                        if (idx > cur && v[k] < best - kSensEps) {
+                            if (myfirst == INT_MAX) {
+                                myfirst = idx;
+                                myv = v[k];
+                            }
+                        } else {
+                            flags &= ~(1u << k);  // best only decreases: dead for good
+                        }
+                    }
+                }
+                // chunks are ordered by lane: the lowest lane with a hit holds the wave's first
+                const unsigned long long mask = __ballot(myfirst != INT_MAX);
+                if (mask != 0ull) {
+                    const int fl = __builtin_amdgcn_readfirstlane(__builtin_ctzll(mask));
+                    first = __builtin_amdgcn_readlane(myfirst, fl);
+                    fv = sens_readlane_f64(myv, fl);
+                }
+            }
+        } else {
+            for (int idx = lo + tid; idx < hi; idx += nt) {
+                if (idx <= cur) continue;
+                const double x = val(idx);
+                if (x < best - kSensEps) {
+                    first = idx;
+                    fv = x;
+                    break;
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const int oi = __shfl_xor(first, off, kWave);
+                const double ov = __shfl_xor(fv, off, kWave);
+                if (oi < first) {
+                    first = oi;
+                    fv = ov;
+                }
+            }
+        }
+        const int bank = (round & 1) * 16;
+        if (lane == 0) {
+            lds_i[bank + wave] = first;
+            lds_v[bank + wave] = fv;
+        }
+        __syncthreads();
+        const int ci = (lane < nw) ? lds_i[bank + lane] : INT_MAX;
+        const double cv = (lane < nw) ? lds_v[bank + lane] : 0.0;
+        first = INT_MAX;
+        for (int w = 0; w < nw; ++w) {
+            const int x = __builtin_amdgcn_readlane(ci, w);
+            if (x < first) {
+                first = x;
+                fv = sens_readlane_f64(cv, w);
+            }
+        }
+        if (first == INT_MAX) break;
+        cur = first;
+        best = fv;
+    }
+    return cur;
+}
+
+// dense copy of one tableau column (the RHS before a run)
+__global__ __launch_bounds__(256) void k_sens_gather_col(const double* __restrict__ T, int ld, int R,
+                                                         int col, double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < R) out[i] = T[(size_t)i * ld + col];
+}
+
+// rhsd = dense RHS column, kept current by k_sens_update.
 __global__ __launch_bounds__(1024) void k_sens_select(double* __restrict__ T, int ld, int R, int C,
                                                       double* __restrict__ rowbuf,
                                                       double* __restrict__ colbuf,
+                                                      const double* __restrict__ rhsd,
                                                       int32_t* __restrict__ basic,
                                                       int32_t* __restrict__ bcount,
                                                       int32_t* __restrict__ log, SensState* st) {
-    __shared__ int lds[16];
-    __shared__ double lds_v[16];
+    __shared__ int lds[32];
+    __shared__ double lds_v[32];
     if (st->status != kRunning) return;
     const int tid = threadIdx.x, nt = blockDim.x;
     const int rhs = C - 1;
@@ -176,24 +326,11 @@ __global__ __launch_bounds__(1024) void k_sens_select(double* __restrict__ T, in
     const int it_d = st->iter_dual, it_p = st->iter_primal;
     __syncthreads();
     int leave = -1, enter = -1, kind = 0;
+    constexpr int K = 16;
 
     if (phase == 0) {
-        // `bi < mostNeg - EPS` over rows ascending (:174-178)
-        double mostNeg = 0.0;
-        for (;;) {
-            int first = INT_MAX;
-            for (int i = 1 + tid; i < R; i += nt) {
-                if (i <= leave) continue;
-                if (T[(size_t)i * ld + rhs] < mostNeg - kSensEps) {
-                    first = i;
-                    break;
-                }
-            }
-            first = sens_block_min_int(first, lds);
-            if (first == INT_MAX) break;
-            leave = first;
-            mostNeg = T[(size_t)leave * ld + rhs];
-        }
+        // `bi < mostNeg - EPS`, mostNeg = 0.0 at the start, rows ascending (:174-178)
+        leave = sens_fold<K>(1, R, 0.0, [&](int i) { return rhsd[i]; }, lds, lds_v);
         if (leave == -1) {
             phase = 1;  // break (:180) -> ReOptimize
             if (tid == 0) st->phase = 1;
@@ -202,31 +339,22 @@ __global__ __launch_bounds__(1024) void k_sens_select(double* __restrict__ T, in
                 if (tid == 0) st->status = LPR_SENS_ITER_LIMIT;
                 return;
             }
-            // `a < -EPS: ratio = cbar / (-a); ratio < best - EPS` over columns ascending (:186-195)
-            double best = INFINITY;
-            for (;;) {
-                int first = INT_MAX;
-                for (int j = tid; j < rhs; j += nt) {
-                    if (j <= enter) continue;
-                    const double a = T[(size_t)leave * ld + j];
-                    if (a < -kSensEps) {
-                        const double ratio = T[j] / (-a);
-                        if (ratio < best - kSensEps) {
-                            first = j;
-                            break;
-                        }
-                    }
-                }
-                first = sens_block_min_int(first, lds);
-                if (first == INT_MAX) break;
-                enter = first;
-                best = T[enter] / (-T[(size_t)leave * ld + enter]);
-            }
+            // `a < -EPS: ratio = cbar / (-a); ratio < best - EPS`, columns ascending (:186-195)
+            const double* __restrict__ lrow = T + (size_t)leave * ld;
+            enter = sens_fold<K>(
+                0, rhs, INFINITY,
+                [&](int j) {
+                    const double a = lrow[j];
+                    return (a < -kSensEps) ? T[j] / (-a) : NAN;
+                },
+                lds, lds_v);
             if (enter == -1) {
                 if (tid == 0) st->status = LPR_SENS_INFEASIBLE;  // :197
                 return;
             }
             if (tid == 0) st->iter_dual = it_d + 1;
+            for (int i = tid; i < R; i += nt) colbuf[i] = T[(size_t)i * ld + enter];
+            __syncthreads();
         }
     }
     if (phase == 1) {
@@ -286,27 +414,17 @@ __global__ __launch_bounds__(1024) void k_sens_select(double* __restrict__ T, in
             return;
         }
         enter = bj;
-        // `a > EPS: ratio = rhs / a; ratio < best - EPS` over rows ascending (:144-150)
-        double best = INFINITY;
-        leave = -1;
-        for (;;) {
-            int first = INT_MAX;
-            for (int i = 1 + tid; i < R; i += nt) {
-                if (i <= leave) continue;
-                const double a = T[(size_t)i * ld + enter];
-                if (a > kSensEps) {
-                    const double ratio = T[(size_t)i * ld + rhs] / a;
-                    if (ratio < best - kSensEps) {
-                        first = i;
-                        break;
-                    }
-                }
-            }
-            first = sens_block_min_int(first, lds);
-            if (first == INT_MAX) break;
-            leave = first;
-            best = T[(size_t)leave * ld + rhs] / T[(size_t)leave * ld + enter];
-        }
+        // one strided pass: the entering column becomes dense (it is also the factor column)
+        for (int i = tid; i < R; i += nt) colbuf[i] = T[(size_t)i * ld + enter];
+        __syncthreads();
+        // `a > EPS: ratio = rhs / a; ratio < best - EPS`, rows ascending (:144-150)
+        leave = sens_fold<K>(
+            1, R, INFINITY,
+            [&](int i) {
+                const double a = colbuf[i];
+                return (a > kSensEps) ? rhsd[i] / a : NAN;
+            },
+            lds, lds_v);
         if (leave == -1) {
             if (tid == 0) st->status = LPR_SENS_UNBOUNDED;  // :151
             return;
@@ -314,17 +432,18 @@ __global__ __launch_bounds__(1024) void k_sens_select(double* __restrict__ T, in
         if (tid == 0) st->iter_primal = it_p + 1;
     }
 
-    // Pivot (:98-119): stage the normalised row and the factor column
+    // Pivot (:98-119): stage the normalised row (the factor column is in colbuf already)
     const double piv = T[(size_t)leave * ld + enter];
     if (fabs(piv) < kSensEps) {
         if (tid == 0) st->status = LPR_SENS_ZERO_PIVOT;  // :101
         return;
     }
     for (int j = tid; j < ld; j += nt) rowbuf[j] = (j < C) ? T[(size_t)leave * ld + j] / piv : 0.0;
-    for (int i = tid; i < R; i += nt) colbuf[i] = T[(size_t)i * ld + enter];
+    __syncthreads();
     if (tid == 0) {
         st->pr = leave;
         st->pc = enter;
+        st->sweep ^= 1;
         st->done += 1;
         const int old = basic[leave - 1];  // basicVars[leaveRow - 1] = enterCol (:117-118)
         if (old >= 0) bcount[old] -= 1;
@@ -340,36 +459,53 @@ __global__ __launch_bounds__(1024) void k_sens_select(double* __restrict__ T, in
     }
 }
 
-// rows i != leaveRow with |factor| < EPS are left untouched (:110)
+// rows i != leaveRow with |factor| < EPS are left untouched (:110).  Tile = TR rows x 256 double2
+// columns; all loads of a lane are issued before its first store, alternate pivots sweep the grid
+// in opposite directions (the tail of one sweep is still in the Infinity Cache for the next).
 template <int TR>
-__global__ __launch_bounds__(256) void k_sens_update(double* __restrict__ T, int ld, int R,
+__global__ __launch_bounds__(256) void k_sens_update(double* __restrict__ T, int ld, int R, int C,
                                                      const double* __restrict__ rowbuf,
                                                      const double* __restrict__ colbuf,
+                                                     double* __restrict__ rhsd,
                                                      const SensState* st) {
     if (st->status != kRunning) return;
     const int ld2 = ld >> 1;
-    const int c2 = blockIdx.x * blockDim.x + threadIdx.x;
-    const int i0 = blockIdx.y * TR;
+    int ct = blockIdx.x, rt = blockIdx.y;
+    if (st->sweep & 1) {
+        ct = gridDim.x - 1 - ct;
+        rt = gridDim.y - 1 - rt;
+    }
+    const int c2 = ct * 256 + threadIdx.x;
+    const int i0 = rt * TR;
     const int r = st->pr;
     if (c2 >= ld2) return;
     const double2 pr2 = reinterpret_cast<const double2*>(rowbuf)[c2];
     double2* __restrict__ T2 = reinterpret_cast<double2*>(T);
+    const int rhs = C - 1;
+    const bool owns_rhs = (c2 == (rhs >> 1));
+    double2 x[TR];
 #pragma unroll
     for (int k = 0; k < TR; ++k) {
         const int i = i0 + k;
-        if (i >= R) break;
-        if (i == r) {
-            T2[(size_t)i * ld2 + c2] = pr2;
-            continue;
+        if (i < R) x[k] = T2[(size_t)i * ld2 + c2];
+    }
+#pragma unroll
+    for (int k = 0; k < TR; ++k) {
+        const int i = i0 + k;
+        if (i < R) {
+            const double f = colbuf[i];
+            const bool is_r = (i == r);
+            if (is_r || !(fabs(f) < kSensEps)) {
+                double2 o;
+                const double px = f * pr2.x;
+                const double py = f * pr2.y;
+                o.x = x[k].x - px;
+                o.y = x[k].y - py;
+                if (is_r) o = pr2;
+                T2[(size_t)i * ld2 + c2] = o;
+                if (owns_rhs) rhsd[i] = (rhs & 1) ? o.y : o.x;
+            }
         }
-        const double f = colbuf[i];
-        if (fabs(f) < kSensEps) continue;
-        double2 x = T2[(size_t)i * ld2 + c2];
-        const double px = f * pr2.x;
-        const double py = f * pr2.y;
-        x.x = x.x - px;
-        x.y = x.y - py;
-        T2[(size_t)i * ld2 + c2] = x;
     }
 }
 
@@ -452,9 +588,9 @@ namespace {
 void sens_free_shape(lpr_sens* s) {
     hipFree(s->T); hipFree(s->rowbuf); hipFree(s->colbuf); hipFree(s->sol); hipFree(s->fold_w);
     hipFree(s->fold_io); hipFree(s->basic); hipFree(s->bcount); hipFree(s->cnt);
-    hipFree(s->rowsum); hipFree(s->cand);
-    s->T = s->rowbuf = s->colbuf = s->sol = s->fold_w = s->fold_io = nullptr;
-    s->basic = s->bcount = s->cnt = s->rowsum = s->cand = nullptr;
+    hipFree(s->rowsum); hipFree(s->cand); hipFree(s->rhsd); hipFree(s->snapT); hipFree(s->snapI);
+    s->T = s->rowbuf = s->colbuf = s->sol = s->fold_w = s->fold_io = s->rhsd = s->snapT = nullptr;
+    s->basic = s->bcount = s->cnt = s->rowsum = s->cand = s->snapI = nullptr;
 }
 
 void sens_release_device(lpr_sens* s) {
@@ -475,7 +611,7 @@ int sens_alloc_aux(lpr_sens* s, int R, int ld, double** T_out) {
     const size_t D = sizeof(double), I = sizeof(int32_t);
     const int rp = align_up(R + 1, 16);
     double *T = nullptr, *rowbuf = nullptr, *colbuf = nullptr, *sol = nullptr, *fw = nullptr,
-           *fio = nullptr;
+           *fio = nullptr, *rhsd = nullptr;
     int32_t *basic = nullptr, *bcount = nullptr, *cnt = nullptr, *rowsum = nullptr,
             *cand = nullptr;
     chk(hipMalloc(&T, (size_t)R * ld * D));
@@ -484,6 +620,7 @@ int sens_alloc_aux(lpr_sens* s, int R, int ld, double** T_out) {
     chk(hipMalloc(&sol, (size_t)ld * D));
     chk(hipMalloc(&fw, (size_t)rp * D));
     chk(hipMalloc(&fio, (size_t)std::max(ld, rp) * D));
+    chk(hipMalloc(&rhsd, (size_t)rp * D));
     chk(hipMalloc(&basic, (size_t)rp * I));
     chk(hipMalloc(&bcount, (size_t)ld * I));
     chk(hipMalloc(&cnt, (size_t)ld * I));
@@ -493,7 +630,7 @@ int sens_alloc_aux(lpr_sens* s, int R, int ld, double** T_out) {
         set_error("device allocation for a sensitivity analyzer (%d x %d) failed: %s", R, ld,
                   hipGetErrorString(err));
         hipFree(T); hipFree(rowbuf); hipFree(colbuf); hipFree(sol); hipFree(fw); hipFree(fio);
-        hipFree(basic); hipFree(bcount); hipFree(cnt); hipFree(rowsum); hipFree(cand);
+        hipFree(rhsd); hipFree(basic); hipFree(bcount); hipFree(cnt); hipFree(rowsum); hipFree(cand);
         return err == hipErrorOutOfMemory ? LPR_OUT_OF_MEMORY : LPR_DEVICE_ERROR;
     }
     hipStream_t st = s->eng->stream;
@@ -504,7 +641,11 @@ int sens_alloc_aux(lpr_sens* s, int R, int ld, double** T_out) {
     // the old aux arrays go, the old T stays with the caller until it has been copied from
     hipFree(s->rowbuf); hipFree(s->colbuf); hipFree(s->sol); hipFree(s->fold_w);
     hipFree(s->fold_io); hipFree(s->basic); hipFree(s->bcount); hipFree(s->cnt);
-    hipFree(s->rowsum); hipFree(s->cand);
+    hipFree(s->rowsum); hipFree(s->cand); hipFree(s->rhsd);
+    hipFree(s->snapT); hipFree(s->snapI);  // a snapshot of the old shape is of no use
+    s->snapT = nullptr;
+    s->snapI = nullptr;
+    s->rhsd = rhsd;
     s->rowbuf = rowbuf; s->colbuf = colbuf; s->sol = sol; s->fold_w = fw; s->fold_io = fio;
     s->basic = basic; s->bcount = bcount; s->cnt = cnt; s->rowsum = rowsum; s->cand = cand;
     *T_out = T;
@@ -586,15 +727,17 @@ int sens_run(lpr_sens* s, bool rebuild, int* outcome) {
     hs->log_n = s->log_n;
     hs->log_cap = s->log_cap;
     LPR_HIP(hipMemcpyAsync(ds, hs, sizeof(SensState), hipMemcpyHostToDevice, st));
-    constexpr int TR = 8;
+    hipLaunchKernelGGL(k_sens_gather_col, dim3((s->R + 255) / 256), dim3(256), 0, st, s->T, s->ld,
+                       s->R, s->C - 1, s->rhsd);
+    constexpr int TR = 32;
     const dim3 ugrid((s->ld / 2 + 255) / 256, (s->R + TR - 1) / TR);
     const int batch = 4;
     for (;;) {
         for (int k = 0; k < batch; ++k) {
             hipLaunchKernelGGL(k_sens_select, dim3(1), dim3(1024), 0, st, s->T, s->ld, s->R, s->C,
-                               s->rowbuf, s->colbuf, s->basic, s->bcount, s->log, ds);
+                               s->rowbuf, s->colbuf, s->rhsd, s->basic, s->bcount, s->log, ds);
             hipLaunchKernelGGL((k_sens_update<TR>), ugrid, dim3(256), 0, st, s->T, s->ld, s->R,
-                               s->rowbuf, s->colbuf, ds);
+                               s->C, s->rowbuf, s->colbuf, s->rhsd, ds);
         }
         LPR_HIP(hipGetLastError());
         LPR_HIP(hipMemcpyAsync(hs, ds, sizeof(SensState), hipMemcpyDeviceToHost, st));
@@ -905,20 +1048,22 @@ int lpr_sens_change_rhs(lpr_sens* s, int32_t k, double new_b, int32_t* outcome) 
     }
     hipStream_t st = s->eng->stream;
     // snapshot (:437-439): tableau, finalZ, basicVars (+ the membership counts that shadow it)
-    double* snapT = nullptr;
-    int32_t* snapI = nullptr;
     const size_t tb = (size_t)s->R * s->ld * sizeof(double);
     const int m = s->R - 1;
     const size_t ib = (size_t)(m + s->ld) * sizeof(int32_t);
-    if (hipMalloc(&snapT, tb) != hipSuccess || hipMalloc(&snapI, ib) != hipSuccess) {
-        hipFree(snapT);
-        set_error("lpr_sens_change_rhs: snapshot allocation failed");
-        return LPR_OUT_OF_MEMORY;
+    if (!s->snapT) {
+        if (hipMalloc(&s->snapT, tb) != hipSuccess || hipMalloc(&s->snapI, ib) != hipSuccess) {
+            hipFree(s->snapT);
+            s->snapT = nullptr;
+            s->snapI = nullptr;
+            set_error("lpr_sens_change_rhs: snapshot allocation failed");
+            return LPR_OUT_OF_MEMORY;
+        }
     }
+    double* snapT = s->snapT;
+    int32_t* snapI = s->snapI;
     auto done = [&](int code) {
         hipStreamSynchronize(st);
-        hipFree(snapT);
-        hipFree(snapI);
         return code;
     };
     if (hipMemcpyAsync(snapT, s->T, tb, hipMemcpyDeviceToDevice, st) != hipSuccess ||
