@@ -115,12 +115,15 @@ typedef struct lpr_solve_opts {
                               lpr_tableau_kernel_stats */
     int32_t batch;         /* pivots queued between host polls of the device status word (0: auto) */
     int32_t variant;       /* rank-1 update kernel variant (0: auto); for tuning only, same bits */
-    int32_t reserved;
+    int32_t block;         /* pivots decided ahead and applied per sweep of the tableau on large
+                              tableaux: 0 auto, 1 one pivot per sweep, 2..8 that many.  The bits
+                              stored are the same for every value (each element goes through the
+                              same sequence of rounded operations, in registers). */
 } lpr_solve_opts;
 
 typedef struct lpr_solve_result {
     int32_t status;        /* lpr_status */
-    int32_t reserved;
+    int32_t block;         /* pivots per sweep this call used (1 on the small-tableau paths) */
     int64_t pivots;        /* pivots performed by THIS call */
     int64_t total_pivots;  /* pivots performed on this tableau so far (== C# `iteration`) */
     double z;              /* T[0, cols-1] at exit (FinalZ, PrimalSimplexSolver.cs:113); the C#

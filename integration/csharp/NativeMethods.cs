@@ -18,13 +18,13 @@ namespace LPR_381_Group_V22.Native
     [StructLayout(LayoutKind.Sequential)]
     internal struct LprSolveOpts
     {
-        public long max_pivots; public int time_kernels; public int batch; public int variant; public int reserved;
+        public long max_pivots; public int time_kernels; public int batch; public int variant; public int block;
     }
 
     [StructLayout(LayoutKind.Sequential)]
     internal struct LprSolveResult
     {
-        public int status; public int reserved; public long pivots; public long total_pivots; public double z;
+        public int status; public int block; public long pivots; public long total_pivots; public double z;
     }
 
     [StructLayout(LayoutKind.Sequential)]

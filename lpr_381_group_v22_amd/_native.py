@@ -49,14 +49,14 @@ class SolveOpts(C.Structure):
         ("time_kernels", C.c_int32),
         ("batch", C.c_int32),
         ("variant", C.c_int32),
-        ("reserved", C.c_int32),
+        ("block", C.c_int32),
     ]
 
 
 class SolveResult(C.Structure):
     _fields_ = [
         ("status", C.c_int32),
-        ("reserved", C.c_int32),
+        ("block", C.c_int32),
         ("pivots", C.c_int64),
         ("total_pivots", C.c_int64),
         ("z", C.c_double),

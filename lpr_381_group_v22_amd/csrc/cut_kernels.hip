@@ -543,7 +543,7 @@ int lpr_dual_solve(lpr_tableau* t, int max_iters, int print_steps, int64_t hard_
     const int st = cut_run_solver(t, kCutDual, max_iters, print_steps, hard_cap, &piv);
     if (st < 0) return st;
     res->status = st;
-    res->reserved = 0;
+    res->block = 1;
     res->pivots = piv;
     res->total_pivots = piv;
     res->z = 0.0;
@@ -565,7 +565,7 @@ int lpr_primal2_solve(lpr_tableau* t, int max_iters, int print_steps, int64_t ha
     const int st = cut_run_solver(t, kCutPrimal2, max_iters, print_steps, hard_cap, &piv);
     if (st < 0) return st;
     res->status = st;
-    res->reserved = 0;
+    res->block = 1;
     res->pivots = piv;
     res->total_pivots = piv;
     res->z = 0.0;

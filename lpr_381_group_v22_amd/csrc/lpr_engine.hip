@@ -35,6 +35,16 @@ void launch_build(lpr_tableau* t, int n, int m, const double* d_obj, const doubl
                   const int32_t* d_ncoef, const int8_t* d_rel, const double* d_rhs, int is_max);
 void launch_synthetic(lpr_tableau* t, int m, int n, uint64_t seed);
 
+// block_kernels.hip
+int blk_max_pivots();
+void blk_release(lpr_tableau* t);
+int blk_ensure(lpr_tableau* t);
+int blk_upload_state(lpr_tableau* t, int64_t iter, int64_t max_iter);
+int blk_set_log_cap(lpr_tableau* t);
+int blk_poll(lpr_tableau* t, int32_t* status, int32_t* pending, int64_t* iter);
+void blk_launch_bootstrap(lpr_tableau* t);
+void blk_launch_heads(lpr_tableau* t, int K);
+void blk_launch_update(lpr_tableau* t, int tr);
 // revised_engine.hip
 void rev_orphan(lpr_revised* s);
 // bb_engine.hip
@@ -110,6 +120,7 @@ static void release_device(lpr_tableau* t) {
     if (t->eng->stream) hipStreamSynchronize(t->eng->stream);
     drop_graph(t);
     lpr_cut_release(t);
+    blk_release(t);
     for (hipEvent_t ev : t->ev) hipEventDestroy(ev);
     t->ev.clear();
     hipFree(t->T);
@@ -180,6 +191,7 @@ static constexpr size_t kFusedBytes = (size_t)16 << 20;
 
 static bool use_fused(const lpr_tableau* t, const lpr_solve_opts& o) {
     if (o.time_kernels) return false;
+    if (o.block >= 2) return false;  // the K-pivots-per-sweep path was asked for explicitly
     if (o.variant == 0x7fff) return false;
     if (o.variant == 0x7ffe) return true;
     if (o.variant != 0) return false;
@@ -279,7 +291,122 @@ static int solve_fused(lpr_tableau* t, const lpr_solve_opts& o, lpr_solve_result
     }
     t->total_pivots = iter;
     res->status = status;
-    res->reserved = 0;
+    res->block = 1;
+    res->pivots = iter - start_iter;
+    res->total_pivots = iter;
+    double z = 0.0;
+    LPR_HIP(hipMemcpyAsync(&z, t->T + (t->cols - 1), sizeof(double), hipMemcpyDeviceToHost, s));
+    LPR_HIP(hipStreamSynchronize(s));
+    res->z = z;
+    return status;
+}
+
+// Large tableaux: K pivots per sweep (block_kernels.hip).  opts.block: 0 = auto, 1 = the
+// one-pivot-per-sweep path, 2..8 = that many.  opts.variant 0x7fff also forces the one-pivot path.
+static constexpr int kDefaultBlock = 4;
+
+static int block_size(const lpr_tableau* t, const lpr_solve_opts& o) {
+    // a specific one-pivot update-kernel variant was asked for (0x60tr = this path, tile rows tr)
+    if (o.variant != 0 && (o.variant & 0xff00) != 0x6000) return 1;
+    int k = o.block;
+    if (k == 0) k = kDefaultBlock;
+    if (k < 1) k = 1;
+    if (k > blk_max_pivots()) k = blk_max_pivots();
+    if (t->rows < 2) k = 1;
+    return k;
+}
+
+static int solve_blocked(lpr_tableau* t, const lpr_solve_opts& o, int K, lpr_solve_result* res) {
+    lpr_engine* e = t->eng;
+    hipStream_t s = e->stream;
+    int rc = blk_ensure(t);
+    if (rc != LPR_OK_OPTIMAL) return rc;
+    const bool timed = o.time_kernels != 0;
+    const int tr = ((o.variant & 0xff00) == 0x6000) ? (o.variant & 0xff) : 16;  // sweep tile rows
+    int nblocks = o.batch > 0 ? (o.batch + K - 1) / K : (default_batch(t) + K - 1) / K;
+    if (nblocks < 1) nblocks = 1;
+    const int64_t start_iter = t->total_pivots;
+    const int64_t max_iter = o.max_pivots > 0 ? start_iter + o.max_pivots : 0;
+    rc = blk_upload_state(t, start_iter, max_iter);
+    if (rc != LPR_OK_OPTIMAL) return rc;
+    blk_launch_bootstrap(t);
+
+    int32_t status = kRunning, pending = kRunning;
+    int64_t iter = start_iter;
+    while (status == kRunning && pending == kRunning) {
+        int nb = nblocks;
+        if (max_iter > 0) {  // no more blocks than the limit can use (+1: the deciding head)
+            const int64_t left = max_iter - iter;
+            const int64_t need = left / K + 1;
+            if (need < nb) nb = (int)need;
+        }
+        const int64_t log_before = t->log_cap;
+        rc = ensure_log(t, iter + (int64_t)nb * K + 1);
+        if (rc != LPR_OK_OPTIMAL) return rc;
+        if (t->log_cap != log_before) {
+            rc = blk_set_log_cap(t);
+            if (rc != LPR_OK_OPTIMAL) return rc;
+        }
+        if (timed) {
+            while ((int)t->ev.size() < 2 * nb) {
+                hipEvent_t ev;
+                LPR_HIP(hipEventCreate(&ev));
+                t->ev.push_back(ev);
+            }
+            for (int k = 0; k < nb; ++k) {
+                blk_launch_heads(t, K);
+                const bool sample = (k % kTimeStride) == 0;
+                if (sample) LPR_HIP(hipEventRecord(t->ev[2 * k], s));
+                blk_launch_update(t, tr);
+                if (sample) LPR_HIP(hipEventRecord(t->ev[2 * k + 1], s));
+            }
+        } else {
+            const int gv = -100 - K * 64 - tr;  // graph key of this path
+            if (!t->graph || t->graph_batch != nb || t->graph_variant != gv) {
+                drop_graph(t);
+                hipGraph_t g = nullptr;
+                LPR_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+                for (int k = 0; k < nb; ++k) {
+                    blk_launch_heads(t, K);
+                    blk_launch_update(t, tr);
+                }
+                LPR_HIP(hipStreamEndCapture(s, &g));
+                hipError_t ierr = hipGraphInstantiate(&t->graph, g, nullptr, nullptr, 0);
+                hipGraphDestroy(g);
+                if (ierr != hipSuccess) {
+                    t->graph = nullptr;
+                    set_error("hipGraphInstantiate failed: %s", hipGetErrorString(ierr));
+                    return LPR_DEVICE_ERROR;
+                }
+                t->graph_batch = nb;
+                t->graph_variant = gv;
+            }
+            LPR_HIP(hipGraphLaunch(t->graph, s));
+        }
+        LPR_HIP(hipGetLastError());
+        int64_t now = iter;
+        rc = blk_poll(t, &status, &pending, &now);
+        if (rc != LPR_OK_OPTIMAL) return rc;
+        const int64_t done = now - iter;
+        if (timed) {  // only sweeps that applied a full block count (K pivots each)
+            const int64_t full = done / K;
+            for (int64_t k = 0; k < full && k < nb; k += kTimeStride) {
+                float ms = 0.f;
+                LPR_HIP(hipEventElapsedTime(&ms, t->ev[2 * k], t->ev[2 * k + 1]));
+                t->timed_total_ms += ms;
+                t->timed_launches += 1;
+            }
+        }
+        iter = now;
+        if (status == kRunning && pending == kRunning && done == 0) {
+            set_error("blocked pivot loop made no progress (device status still running)");
+            return LPR_DEVICE_ERROR;
+        }
+    }
+    if (status == kRunning) status = pending;  // decided by the last block, not yet published
+    t->total_pivots = iter;
+    res->status = status;
+    res->block = K;
     res->pivots = iter - start_iter;
     res->total_pivots = iter;
     double z = 0.0;
@@ -530,6 +657,10 @@ int lpr_primal_solve(lpr_tableau* t, const lpr_solve_opts* opts, lpr_solve_resul
     LPR_HIP(hipSetDevice(e->device));
 
     if (use_fused(t, o)) return solve_fused(t, o, res);
+    {
+        const int K = block_size(t, o);
+        if (K > 1) return solve_blocked(t, o, K, res);
+    }
     const int variant = (o.variant > 0 && o.variant < 0x7000) ? o.variant - 1 : default_variant(t);
     int batch = o.batch > 0 ? o.batch : default_batch(t);
     const bool timed = o.time_kernels != 0;
@@ -627,7 +758,7 @@ int lpr_primal_solve(lpr_tableau* t, const lpr_solve_opts* opts, lpr_solve_resul
     }
     t->total_pivots = iter;
     res->status = status;
-    res->reserved = 0;
+    res->block = 1;
     res->pivots = iter - start_iter;
     res->total_pivots = iter;
     double z = 0.0;

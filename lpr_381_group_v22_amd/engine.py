@@ -122,9 +122,10 @@ class Tableau:
 
     # ---- the pivot loop -----------------------------------------------------------------
     def solve(self, max_pivots: int = 0, time_kernels: bool = False, batch: int = 0,
-              variant: int = 0) -> N.SolveResult:
+              variant: int = 0, block: int = 0) -> N.SolveResult:
+        """block: pivots decided ahead and applied per sweep on large tableaux (0 auto, 1..8)."""
         opts = N.SolveOpts(max_pivots=max_pivots, time_kernels=1 if time_kernels else 0,
-                           batch=batch, variant=variant, reserved=0)
+                           batch=batch, variant=variant, block=block)
         res = N.SolveResult()
         N.check(N.lib.lpr_primal_solve(self._h, C.byref(opts), C.byref(res)), "lpr_primal_solve")
         return res
@@ -257,7 +258,7 @@ class RevisedState:
 
     def solve(self, max_pivots: int = 0, batch: int = 0) -> N.RevisedResult:
         opts = N.SolveOpts(max_pivots=max_pivots, time_kernels=0, batch=batch, variant=0,
-                           reserved=0)
+                           block=0)
         res = N.RevisedResult()
         N.check(N.lib.lpr_revised_solve(self._h, C.byref(opts), C.byref(res)),
                 "lpr_revised_solve")

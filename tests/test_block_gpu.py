@@ -1,0 +1,182 @@
+"""GPU parity tests of the K-pivots-per-sweep path (csrc/block_kernels.hip, opts.block): deciding
+K pivots ahead from O(R + C) data and applying them in one sweep must give the same status, pivot
+log, basis and tableau BITS as the oracle's one-pivot-at-a-time loop, for every K, every stop
+reason and every way a pivot limit can cut a block."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import lp_cases
+
+pytestmark = pytest.mark.gpu
+
+BLOCKS = [2, 3, 4, 8]
+
+
+def _build(oracle, case):
+    obj, cons, is_max = case
+    o, A, ncoef, rel, rhs = lp_cases.flatten(obj, cons)
+    return oracle.primal_build(o, A, rel, rhs, is_max, ncoef)
+
+
+@pytest.mark.parametrize("block", BLOCKS)
+def test_named_cases_match_oracle(engine, oracle, block):
+    from lpr_381_group_v22_amd import Tableau
+    statuses = set()
+    for name, case in lp_cases.all_cases():
+        T, basis = _build(oracle, case)
+        if T.shape[0] < 2:
+            continue
+        tab = Tableau.from_array(engine, T, basis)
+        st, piv, log = oracle.primal_solve(T, basis, 5000)
+        res = tab.solve(max_pivots=5000, block=block)
+        assert res.block == block, name
+        assert res.status == st and res.pivots == piv, (name, res.status, st, res.pivots, piv)
+        assert tab.pivot_log().tolist() == log.tolist(), name
+        assert tab.basis().tolist() == basis.tolist(), name
+        assert tab.read().tobytes() == T.tobytes(), name
+        statuses.add(st)
+        tab.destroy()
+    assert {0, 1} <= statuses
+
+
+@pytest.mark.parametrize("block", BLOCKS)
+def test_every_pivot_limit_cuts_the_block_correctly(engine, oracle, block):
+    """max_pivots = 0..17 on the same LP: the limit lands on every position inside a block."""
+    from lpr_381_group_v22_amd import Tableau
+    m, n, seed = 40, 64, 3
+    T0, b0 = oracle.gen_dense_tableau(m, n, seed)
+    for limit in range(1, 18):
+        T, basis = T0.copy(), b0.copy()
+        st, piv, log = oracle.primal_solve(T, basis, limit)
+        tab = Tableau.synthetic(engine, m, n, seed)
+        res = tab.solve(max_pivots=limit, block=block, batch=5)
+        assert res.status == st and res.pivots == piv, (limit, res.status, st, res.pivots, piv)
+        assert tab.pivot_log().tolist() == log.tolist(), limit
+        assert tab.read().tobytes() == T.tobytes(), limit
+        tab.destroy()
+
+
+@pytest.mark.parametrize("block", BLOCKS)
+def test_resume_after_pivot_limit(engine, oracle, block):
+    from lpr_381_group_v22_amd import Tableau
+    m, n, seed = 48, 96, 2
+    T, basis = oracle.gen_dense_tableau(m, n, seed)
+    st, piv, log = oracle.primal_solve(T, basis)
+    tab = Tableau.synthetic(engine, m, n, seed)
+    total = 0
+    while True:
+        res = tab.solve(max_pivots=7, batch=3, block=block)
+        total += res.pivots
+        assert res.total_pivots == total
+        if res.status != 5:
+            break
+        assert res.pivots == 7
+    assert res.status == st and total == piv
+    assert tab.pivot_log().tolist() == log.tolist()
+    assert tab.basis().tolist() == basis.tolist()
+    assert tab.read().tobytes() == T.tobytes()
+    tab.destroy()
+
+
+@pytest.mark.parametrize("block,timed", [(2, False), (4, True), (8, False), (5, True)])
+def test_medium_dense_lp_full_solve(engine, oracle, block, timed):
+    """m=200, n=333 to optimality (hundreds of pivots), graph replay and eager+events."""
+    from lpr_381_group_v22_amd import Tableau
+    m, n, seed = 200, 333, 11
+    T, basis = oracle.gen_dense_tableau(m, n, seed)
+    st, piv, log = oracle.primal_solve(T, basis, 20000)
+    tab = Tableau.synthetic(engine, m, n, seed)
+    res = tab.solve(max_pivots=20000, block=block, time_kernels=timed)
+    assert res.status == st == 0 and res.pivots == piv
+    assert tab.pivot_log(1 << 16).tolist() == log.tolist()
+    assert tab.basis().tolist() == basis.tolist()
+    assert tab.read().tobytes() == T.tobytes()
+    if timed:
+        launches, total_ms, avg_ms = tab.kernel_stats()
+        assert launches > 0 and avg_ms > 0
+    tab.destroy()
+
+
+@pytest.mark.parametrize("tr", [8, 16, 32])
+def test_sweep_tile_shapes_give_identical_bits(engine, oracle, tr):
+    from lpr_381_group_v22_amd import Tableau
+    m, n, seed = 150, 260, 5
+    T, basis = oracle.gen_dense_tableau(m, n, seed)
+    st, piv, log = oracle.primal_solve(T, basis, 90)
+    tab = Tableau.synthetic(engine, m, n, seed)
+    res = tab.solve(max_pivots=90, block=4, variant=0x6000 | tr)
+    assert res.status == st and res.pivots == piv and res.block == 4
+    assert tab.pivot_log().tolist() == log.tolist()
+    assert tab.read().tobytes() == T.tobytes()
+    tab.destroy()
+
+
+def test_repeated_rows_and_columns_inside_a_block(engine, oracle):
+    """Degenerate / tie-heavy LPs: the same row leaves twice within one block, a column re-enters,
+    ties in both arg-mins -- the chains through earlier pivots must reproduce them exactly."""
+    from lpr_381_group_v22_amd import Tableau
+    seen_repeat = seen_col_repeat = False
+    cases = [lp_cases.tie_heavy(18, 14, seed) for seed in range(6)] + \
+        [lp_cases.tie_heavy(8, 12, seed) for seed in (2, 10)] + \
+        [lp_cases.klee_minty_bounded(d) for d in (4, 6, 8)]
+    for seed, case in enumerate(cases):
+        T, basis = _build(oracle, case)
+        tab = Tableau.from_array(engine, T, basis)
+        st, piv, log = oracle.primal_solve(T, basis, 400)
+        rows = [r for r, _ in log.tolist()]
+        cols = [c for _, c in log.tolist()]
+        for k in range(0, len(rows), 8):
+            seen_repeat |= len(set(rows[k:k + 8])) < len(rows[k:k + 8])
+            seen_col_repeat |= len(set(cols[k:k + 8])) < len(cols[k:k + 8])
+        res = tab.solve(max_pivots=400, block=8)
+        assert res.status == st and res.pivots == piv, seed
+        assert tab.pivot_log().tolist() == log.tolist(), seed
+        assert tab.read().tobytes() == T.tobytes(), seed
+        tab.destroy()
+    assert seen_repeat and seen_col_repeat, "fixtures no longer repeat a pivot row / column inside a block"
+
+
+def test_wide_and_tall_shapes(engine, oracle):
+    """ld wider than one head trip (G * 256 double2 < ld / 2) and tall thin tableaux."""
+    from lpr_381_group_v22_amd import Tableau
+    for (m, n, seed) in [(6, 20000, 1), (3000, 10, 2), (2, 5000, 4), (1, 1, 3)]:
+        T, basis = oracle.gen_dense_tableau(m, n, seed)
+        st, piv, log = oracle.primal_solve(T, basis, 600)
+        tab = Tableau.synthetic(engine, m, n, seed)
+        res = tab.solve(max_pivots=600, block=4)
+        assert res.status == st and res.pivots == piv, (m, n)
+        assert tab.pivot_log().tolist() == log.tolist(), (m, n)
+        assert tab.basis().tolist() == basis.tolist(), (m, n)
+        assert tab.read().tobytes() == T.tobytes(), (m, n)
+        tab.destroy()
+
+
+def test_north_star_size_blocked_equals_one_pivot_path(engine, oracle):
+    """m=4096, n=8192: the first 8 pivots against the oracle, then 96 more against the
+    one-pivot-per-sweep path (same device, different kernels): same log, same tableau hash."""
+    from lpr_381_group_v22_amd import Tableau
+    m, n, seed = 4096, 8192, 0
+    T, basis = oracle.gen_dense_tableau(m, n, seed)
+    st, piv, log = oracle.primal_solve(T, basis, 8)
+    a = Tableau.synthetic(engine, m, n, seed)
+    res = a.solve(max_pivots=8, block=8)
+    assert res.status == st == 5 and res.pivots == 8 and res.block == 8
+    assert a.pivot_log().tolist() == log.tolist()
+    assert hashlib.sha256(a.read().tobytes()).hexdigest() == \
+        hashlib.sha256(T.tobytes()).hexdigest()
+    del T
+    b = Tableau.synthetic(engine, m, n, seed)
+    b.solve(max_pivots=8, block=1)
+    ra = a.solve(max_pivots=96)            # auto block
+    rb = b.solve(max_pivots=96, block=1)
+    assert ra.block > 1 and rb.block == 1
+    assert ra.pivots == rb.pivots == 96 and ra.z == rb.z
+    assert a.pivot_log().tolist() == b.pivot_log().tolist()
+    assert a.basis().tolist() == b.basis().tolist()
+    ha = hashlib.sha256(a.read().tobytes()).hexdigest()
+    hb = hashlib.sha256(b.read().tobytes()).hexdigest()
+    assert ha == hb
+    a.destroy()
+    b.destroy()
