@@ -51,10 +51,11 @@ def _oracle():
     return Oracle()
 
 
-def _pmc_traffic(m: int, n: int) -> dict:
-    """HBM-side bytes of one k_update launch from the rocprofv3 PMC passes (FETCH_SIZE doubled for
+def _pmc_traffic(m: int, n: int, block: int = 1) -> dict:
+    """HBM-side bytes of one sweep launch from the rocprofv3 PMC passes (FETCH_SIZE doubled for
     gfx950 wide reads + WRITE_SIZE, separate --pmc runs).  Counters cannot be read from inside the
-    process, so the newest summary committed under profiles/ for this workload is reported."""
+    process, so the newest summary committed under profiles/ for this workload (same tableau, same
+    pivots per sweep) is reported."""
     import glob
     best = {}
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_pmc_summary.json"))):
@@ -62,7 +63,8 @@ def _pmc_traffic(m: int, n: int) -> dict:
             with open(path) as f:
                 d = json.load(f)
             t = d.get("k_update_traffic_per_launch", {})
-            if t.get("algorithmic_bytes") == 2 * 8 * (m + 1) * (n + m + 1):
+            if t.get("algorithmic_bytes") == block * 2 * 8 * (m + 1) * (n + m + 1) and \
+                    int(t.get("pivots_per_launch", 1)) == block:
                 best = {"traffic": int(t["hbm_side_bytes"]),
                         "traffic_source": os.path.relpath(path, ROOT)}
         except (OSError, ValueError, KeyError):
@@ -130,13 +132,14 @@ def run_primal(args, D: Dist):
     tab = pkg.Tableau.synthetic(eng, m, n, D.rank)  # one LP replica per rank (seed = rank)
     timed = not args.no_kernel_timing
     if W > 0:
-        res = tab.solve(max_pivots=W, time_kernels=False, variant=args.variant)
+        res = tab.solve(max_pivots=W, time_kernels=False, variant=args.variant, block=args.block)
         if res.pivots != W:
             raise SystemExit(f"warm-up ended after {res.pivots} pivots (status {res.status})")
     k0 = tab.kernel_stats()
     D.barrier(eng)
     t0 = time.perf_counter()
-    res = tab.solve(max_pivots=K, time_kernels=timed, variant=args.variant)
+    res = tab.solve(max_pivots=K, time_kernels=timed, variant=args.variant, block=args.block)
+    block = max(1, res.block)  # pivots applied per sweep of the tableau
     D.barrier(eng)
     dt = time.perf_counter() - t0
     if res.pivots != K:
@@ -152,15 +155,25 @@ def run_primal(args, D: Dist):
         value = D.world * K / dt_max
         roof = None
         if kern_ms:
-            achieved = bytes_per_pivot / (kern_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": "k_update (rank-1 row elimination)",
+            # algorithmic bytes of one launch = SURVEY 8(d)'s 2*8*R*C per pivot x the pivots that
+            # launch applies.  With block > 1 the sweep still moves each element once, so the
+            # algorithmic rate can exceed the HBM peak; `traffic` is what physically moved.
+            achieved = block * bytes_per_pivot / (kern_ms * 1e-3) / 1e9
+            kname = "k_update (rank-1 row elimination)" if block == 1 else \
+                f"k_blk_update ({block} pivots per sweep, each element through {block} " \
+                f"rounded multiply-subtract steps in registers)"
+            roof = {"bound": "hbm", "kernel": kname,
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                    "bytes_per_launch": bytes_per_pivot,
+                    "pivots_per_launch": block,
+                    "bytes_per_launch": block * bytes_per_pivot,
                     "avg_launch_ms": round(kern_ms, 6), "launches": launches,
-                    "event_sampling": "every 4th k_update launch of the timed region",
+                    "event_sampling": "every 4th sweep launch of the timed region",
                     "traffic": None}
-            roof.update(_pmc_traffic(m, n))
+            roof.update(_pmc_traffic(m, n, block))
+            if roof.get("traffic"):
+                roof["hbm_side_frac"] = round(roof["traffic"] / (kern_ms * 1e-3) / 1e9
+                                              / HBM_PEAK_GBPS, 4)
         cpu = None
         if D.world == 1 and args.cpu_pivots != 0:
             cp = args.cpu_pivots
@@ -189,6 +202,7 @@ def run_primal(args, D: Dist):
                                    f"({R * C * 8 / 1e6:.1f} MB), one LP replica per GPU",
                        "m": m, "n": n, "rows": R, "cols": C, "seed": "rank",
                        "parallelism": f"replica{D.world}", "update_variant": args.variant,
+                       "pivots_per_sweep": block,
                        "launch": "eager+events" if timed else "hipGraph"},
             "roofline": roof, "cpu_baseline": cpu,
         }
@@ -394,6 +408,8 @@ def main() -> int:
     ap.add_argument("--m", type=int, default=4096)
     ap.add_argument("--n", type=int, default=8192)
     ap.add_argument("--variant", type=int, default=0, help="rank-1 update kernel variant (0=auto)")
+    ap.add_argument("--block", type=int, default=0,
+                    help="pivots decided ahead and applied per sweep (0=auto, 1..8)")
     ap.add_argument("--cpu-pivots", type=int, default=-1,
                     help="pivots of the CPU baseline sample (-1: sized for ~15 s, 0: skip)")
     ap.add_argument("--no-kernel-timing", action="store_true",

@@ -33,7 +33,7 @@
 namespace lpr {
 
 constexpr int kBlkMax = 8;       // pivots per sweep, upper bound (register budget of the sweep)
-constexpr int kBlkHeadNT = 256;  // threads per head workgroup
+constexpr int kBlkHeadNT = 512;  // threads per head workgroup
 
 struct BlockState {
     int32_t status;        // kRunning or the final lpr_status
@@ -92,25 +92,42 @@ __global__ __launch_bounds__(1024) void k_blk_bootstrap(const double* __restrict
 // ------------------------------------------------------------------------------------------
 // Column e_q of T^(q-1), q >= 2: the strided gather from the tableau in memory, spread over many
 // workgroups (one CU cannot walk 4097 rows x 98 KB stride quickly), then through pivots 1..q-1.
+// Two dependent memory trips: everything whose address is known up front (control block, both
+// partial banks, this row's factors) is requested first, then T[i, e] and p_s[e].
 __global__ __launch_bounds__(128) void k_blk_gather(const double* __restrict__ T, int ld, int R,
                                                     int q, const double* __restrict__ prow,
                                                     double* __restrict__ fcol, int Rp,
                                                     const BlockState* st,
                                                     const ZPart* __restrict__ zparts, int G) {
-    if (st->status != kRunning || st->pending != kRunning) return;
-    const int64_t it0 = st->iter;
-    const int e = reduce_zparts(zparts + ((it0 + q - 1) & 1) * kMaxHeadGroups, G).i;
-    if (e < 0) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= R) return;
+    const int32_t status = st->status;
+    const int32_t pending = st->pending;
+    const int64_t it0 = st->iter;
+    const Cand e0 = reduce_zparts(zparts, G);
+    const Cand e1 = reduce_zparts(zparts + kMaxHeadGroups, G);
+    int rs[kBlkMax];
+    double f[kBlkMax];
+#pragma unroll
+    for (int s = 0; s < kBlkMax; ++s) {
+        rs[s] = (s < q - 1) ? st->r[s] : -1;
+        f[s] = (s < q - 1 && i < R) ? fcol[(size_t)s * Rp + i] : 0.0;
+    }
+    if (status != kRunning || pending != kRunning) return;
+    const int e = (((it0 + q - 1) & 1) ? e1 : e0).i;
+    if (e < 0 || i >= R) return;
     double c = T[(size_t)i * ld + e];
-    for (int s = 0; s < q - 1; ++s) {
-        const double pe = prow[(size_t)s * ld + e];
-        if (i == st->r[s]) {
-            c = pe;
-        } else {
-            const double prod = fcol[(size_t)s * Rp + i] * pe;
-            c = c - prod;
+    double pe[kBlkMax];
+#pragma unroll
+    for (int s = 0; s < kBlkMax; ++s) pe[s] = (s < q - 1) ? prow[(size_t)s * ld + e] : 0.0;
+#pragma unroll
+    for (int s = 0; s < kBlkMax; ++s) {
+        if (s < q - 1) {
+            if (i == rs[s]) {
+                c = pe[s];
+            } else {
+                const double prod = f[s] * pe[s];
+                c = c - prod;
+            }
         }
     }
     fcol[(size_t)(q - 1) * Rp + i] = c;
@@ -126,6 +143,11 @@ __global__ __launch_bounds__(128) void k_blk_gather(const double* __restrict__ T
 //   4. by row slices: b^(q) -> bvec[q & 1]; the factor column of pivot 1 is copied out of
 //      next_col (the sweep overwrites next_col while it still needs the factors).
 // Only workgroup 0 writes the control block, and only fields no workgroup of this launch reads.
+// Memory trips: (1) control block, both banks, the dense column / RHS, this lane's slices of the
+// earlier pivot rows and of the Z row -- all addresses known up front; (2) what depends on r_q:
+// the row itself and the factors f_s[r_q].
+constexpr int kBlkHeadU = 9;  // dense-vector elements preloaded per lane (9 * 512 >= 4097)
+
 __global__ __launch_bounds__(kBlkHeadNT) void k_blk_head(
     const double* __restrict__ T, int ld, int R, int C, int q, double* __restrict__ prow,
     double* __restrict__ fcol, int Rp, const double* __restrict__ next_col,
@@ -138,19 +160,52 @@ __global__ __launch_bounds__(kBlkHeadNT) void k_blk_head(
     const int tid = threadIdx.x, nt = blockDim.x;
     const int g = blockIdx.x;
     const bool lead = (g == 0);
+    const int ld2 = ld >> 1;
+    const int rhs = C - 1;
+    const double2* __restrict__ T2 = reinterpret_cast<const double2*>(T);
+    double2* __restrict__ prow2 = reinterpret_cast<double2*>(prow);
+    double2* __restrict__ zrow2 = reinterpret_cast<double2*>(zrow);
+    const double* __restrict__ col = (q == 1) ? next_col : fcol + (size_t)(q - 1) * Rp;
+    const double* __restrict__ bprev = (q == 1) ? next_rhs : bvec + (size_t)((q - 1) & 1) * Rp;
+    double* __restrict__ bnew = bvec + (size_t)(q & 1) * Rp;
+
+    // ---- trip 1 ----
     const int32_t status = st->status;
     const int32_t pending = st->pending;
     const int64_t it0 = st->iter;
     const int64_t mx = st->max_iter;
+    const Cand e0 = reduce_zparts(zparts, G);
+    const Cand e1 = reduce_zparts(zparts + kMaxHeadGroups, G);
+    double a0[kBlkHeadU], b0[kBlkHeadU];
+#pragma unroll
+    for (int u = 0; u < kBlkHeadU; ++u) {
+        const int i = tid + u * nt;
+        a0[u] = (i < R) ? col[i] : 0.0;
+        b0[u] = (i < R) ? bprev[i] : 0.0;
+    }
+    const int c2_first = g * nt + tid;
+    const bool have_c2 = c2_first < ld2;
+    int rs[kBlkMax];
+    double prs[kBlkMax];
+    double2 ps0[kBlkMax];
+#pragma unroll
+    for (int s = 0; s < kBlkMax; ++s) {
+        rs[s] = (s < q - 1) ? st->r[s] : -1;
+        prs[s] = (s < q - 1) ? prow[(size_t)s * ld + rhs] : 0.0;
+        ps0[s] = (s < q - 1 && have_c2) ? prow2[(size_t)s * ld2 + c2_first]
+                                        : make_double2(0.0, 0.0);
+    }
+    double2 z0 = make_double2(0.0, 0.0);
+    if (have_c2) z0 = (q == 1) ? T2[c2_first] : zrow2[c2_first];
+
     if (status != kRunning) return;
     if (pending != kRunning) {
         if (q == 1 && lead && tid == 0) st->status = pending;  // the block before ended the solve
         return;
     }
     const int64_t pidx = it0 + q - 1;  // index of this pivot in the solve
-    const ZPart* __restrict__ bank_in = zparts + (pidx & 1) * kMaxHeadGroups;
     ZPart* __restrict__ bank_out = zparts + ((pidx + 1) & 1) * kMaxHeadGroups;
-    const int e = reduce_zparts(bank_in, G).i;
+    const int e = ((pidx & 1) ? e1 : e0).i;
     if (e < 0) {
         if (lead && tid == 0) {
             st->pending = LPR_OK_OPTIMAL;
@@ -158,25 +213,38 @@ __global__ __launch_bounds__(kBlkHeadNT) void k_blk_head(
         }
         return;
     }
-    const double* __restrict__ col = (q == 1) ? next_col : fcol + (size_t)(q - 1) * Rp;
-    const double* __restrict__ bprev = (q == 1) ? next_rhs : bvec + (size_t)((q - 1) & 1) * Rp;
-    double* __restrict__ bnew = bvec + (size_t)(q & 1) * Rp;
 
     // ---- FindLeavingVariable on the dense vectors ----
     Cand c;
     c.v = DBL_MAX;
     c.i = -1;
     double a_of_best = 0.0;
-    for (int i = tid; i < R; i += nt) {
-        const double a = col[i];
-        const double b = bprev[i];
-        if (i == 0) lds_p[1] = a;
-        if (i >= 1 && a > 1e-9) {
-            const double ratio = b / a;
-            if (ratio >= 0 && ratio < c.v) {
-                c.v = ratio;
-                c.i = i;
-                a_of_best = a;
+    for (int i0 = tid; i0 < R; i0 += kBlkHeadU * nt) {
+        double a[kBlkHeadU], b[kBlkHeadU];
+#pragma unroll
+        for (int u = 0; u < kBlkHeadU; ++u) {
+            const int i = i0 + u * nt;
+            if (i0 == tid) {
+                a[u] = a0[u];
+                b[u] = b0[u];
+            } else {
+                a[u] = (i < R) ? col[i] : 0.0;
+                b[u] = (i < R) ? bprev[i] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kBlkHeadU; ++u) {
+            const int i = i0 + u * nt;
+            if (i < R) {
+                if (i == 0) lds_p[1] = a[u];
+                if (i >= 1 && a[u] > 1e-9) {
+                    const double ratio = b[u] / a[u];
+                    if (ratio >= 0 && ratio < c.v) {
+                        c.v = ratio;
+                        c.i = i;
+                        a_of_best = a[u];
+                    }
+                }
             }
         }
     }
@@ -198,34 +266,34 @@ __global__ __launch_bounds__(kBlkHeadNT) void k_blk_head(
         return;
     }
     if (my_best == r) lds_p[0] = a_of_best;  // exactly one lane owns row r
+
+    // ---- trip 2: what the earlier pivots of the block do to row r, and the row itself ----
+    double fr[kBlkMax];
+#pragma unroll
+    for (int s = 0; s < kBlkMax; ++s) fr[s] = (s < q - 1) ? fcol[(size_t)s * Rp + r] : 0.0;
+    double wr = T[(size_t)r * ld + rhs];
+    double2 w0 = have_c2 ? T2[(size_t)r * ld2 + c2_first] : make_double2(0.0, 0.0);
     __syncthreads();
     const double p = lds_p[0];
     const double f0 = lds_p[1];
 
-    // what the earlier pivots of the block do to row r
-    int rs[kBlkMax];
-    double fr[kBlkMax];
-#pragma unroll
-    for (int s = 0; s < kBlkMax; ++s) {
-        rs[s] = (s < q - 1) ? st->r[s] : -1;
-        fr[s] = (s < q - 1) ? fcol[(size_t)s * Rp + r] : 0.0;
-    }
-
     // ---- row r through pivots 1..q-1, normalise, next Z row, partial arg-min ----
-    const int ld2 = ld >> 1;
-    const double2* __restrict__ T2 = reinterpret_cast<const double2*>(T);
-    double2* __restrict__ prow2 = reinterpret_cast<double2*>(prow);
-    double2* __restrict__ zrow2 = reinterpret_cast<double2*>(zrow);
     Cand n;
     n.v = 0.0;
     n.i = -1;
-    for (int c2 = g * nt + tid; c2 < ld2; c2 += G * nt) {
-        double2 w = T2[(size_t)r * ld2 + c2];
-        double2 z = (q == 1) ? T2[c2] : zrow2[c2];
+    for (int c2 = c2_first; c2 < ld2; c2 += G * nt) {
+        double2 w, z;
+        if (c2 == c2_first) {
+            w = w0;
+            z = z0;
+        } else {
+            w = T2[(size_t)r * ld2 + c2];
+            z = (q == 1) ? T2[c2] : zrow2[c2];
+        }
 #pragma unroll
         for (int s = 0; s < kBlkMax; ++s) {
             if (s < q - 1) {
-                const double2 ps = prow2[(size_t)s * ld2 + c2];
+                const double2 ps = (c2 == c2_first) ? ps0[s] : prow2[(size_t)s * ld2 + c2];
                 if (r == rs[s]) {
                     w = ps;
                 } else {
@@ -258,16 +326,13 @@ __global__ __launch_bounds__(kBlkHeadNT) void k_blk_head(
     n = block_cand_min(n, lds_v, lds_i);
 
     // ---- RHS column after this pivot (and the factor column of pivot 1) ----
-    const int rhs = C - 1;
-    double wr = T[(size_t)r * ld + rhs];
 #pragma unroll
     for (int s = 0; s < kBlkMax; ++s) {
         if (s < q - 1) {
-            const double prs = prow[(size_t)s * ld + rhs];
             if (r == rs[s]) {
-                wr = prs;
+                wr = prs[s];
             } else {
-                const double prod = fr[s] * prs;
+                const double prod = fr[s] * prs[s];
                 wr = wr - prod;
             }
         }

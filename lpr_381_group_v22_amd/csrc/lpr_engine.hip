@@ -303,7 +303,7 @@ static int solve_fused(lpr_tableau* t, const lpr_solve_opts& o, lpr_solve_result
 
 // Large tableaux: K pivots per sweep (block_kernels.hip).  opts.block: 0 = auto, 1 = the
 // one-pivot-per-sweep path, 2..8 = that many.  opts.variant 0x7fff also forces the one-pivot path.
-static constexpr int kDefaultBlock = 4;
+static constexpr int kDefaultBlock = 8;
 
 static int block_size(const lpr_tableau* t, const lpr_solve_opts& o) {
     // a specific one-pivot update-kernel variant was asked for (0x60tr = this path, tile rows tr)
@@ -322,7 +322,7 @@ static int solve_blocked(lpr_tableau* t, const lpr_solve_opts& o, int K, lpr_sol
     int rc = blk_ensure(t);
     if (rc != LPR_OK_OPTIMAL) return rc;
     const bool timed = o.time_kernels != 0;
-    const int tr = ((o.variant & 0xff00) == 0x6000) ? (o.variant & 0xff) : 16;  // sweep tile rows
+    const int tr = ((o.variant & 0xff00) == 0x6000) ? (o.variant & 0xff) : 8;  // sweep tile rows
     int nblocks = o.batch > 0 ? (o.batch + K - 1) / K : (default_batch(t) + K - 1) / K;
     if (nblocks < 1) nblocks = 1;
     const int64_t start_iter = t->total_pivots;
