@@ -103,6 +103,7 @@ struct lpr_tableau {
     int graph_batch = 0;
     int graph_variant = -1;
     const double* graph_T = nullptr;
+    void* ov = nullptr;               // lpr_overlap_ctx of the overlapped K-pivot path (overlap_kernels.hip)
     void* blk = nullptr;              // lpr_block_ctx of the K-pivots-per-sweep path (block_kernels.hip)
     void* cut = nullptr;              // lpr_cut_ctx of the cutting-plane side path (cut_kernels.hip)  // T at capture time (the fused path alternates T / T2)
 };

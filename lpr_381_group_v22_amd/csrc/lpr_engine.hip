@@ -45,6 +45,18 @@ int blk_poll(lpr_tableau* t, int32_t* status, int32_t* pending, int64_t* iter);
 void blk_launch_bootstrap(lpr_tableau* t);
 void blk_launch_heads(lpr_tableau* t, int K);
 void blk_launch_update(lpr_tableau* t, int tr);
+// overlap_kernels.hip
+int ov_max_pivots();
+void ov_release(lpr_tableau* t);
+int ov_ensure(lpr_tableau* t);
+int ov_begin(lpr_tableau* t, int64_t iter, int64_t max_iter);
+int ov_set_log(lpr_tableau* t, int parity);
+void ov_launch_step(lpr_tableau* t, int K, int tr, int lp);
+void ov_launch_heads(lpr_tableau* t, int K);
+void ov_launch_sweep(lpr_tableau* t, int tr);
+int ov_poll(lpr_tableau* t, int parity, int32_t* status, int32_t* cur, int64_t* applied,
+            int32_t* error);
+void ov_adopt_buffer(lpr_tableau* t, int cur);
 // revised_engine.hip
 void rev_orphan(lpr_revised* s);
 // bb_engine.hip
@@ -121,6 +133,7 @@ static void release_device(lpr_tableau* t) {
     drop_graph(t);
     lpr_cut_release(t);
     blk_release(t);
+    ov_release(t);
     for (hipEvent_t ev : t->ev) hipEventDestroy(ev);
     t->ev.clear();
     hipFree(t->T);
@@ -307,11 +320,14 @@ static constexpr int kDefaultBlock = 8;
 
 static int block_size(const lpr_tableau* t, const lpr_solve_opts& o) {
     // a specific one-pivot update-kernel variant was asked for (0x60tr = this path, tile rows tr)
-    if (o.variant != 0 && (o.variant & 0xff00) != 0x6000) return 1;
+    if (o.variant != 0 && (o.variant & 0xff00) != 0x6000 && (o.variant & 0xff00) != 0x5000 &&
+        (o.variant & 0xff00) != 0x4000)
+        return 1;
     int k = o.block;
     if (k == 0) k = kDefaultBlock;
     if (k < 1) k = 1;
-    if (k > blk_max_pivots()) k = blk_max_pivots();
+    const int kmax = ((o.variant & 0xff00) == 0x6000) ? blk_max_pivots() : ov_max_pivots();
+    if (k > kmax) k = kmax;
     if (t->rows < 2) k = 1;
     return k;
 }
@@ -409,6 +425,125 @@ static int solve_blocked(lpr_tableau* t, const lpr_solve_opts& o, int K, lpr_sol
     res->block = K;
     res->pivots = iter - start_iter;
     res->total_pivots = iter;
+    double z = 0.0;
+    LPR_HIP(hipMemcpyAsync(&z, t->T + (t->cols - 1), sizeof(double), hipMemcpyDeviceToHost, s));
+    LPR_HIP(hipStreamSynchronize(s));
+    res->z = z;
+    return status;
+}
+
+// Large tableaux, default: K pivots per sweep with the next block's loop heads running inside the
+// same launch as the current block's (out-of-place) sweep -- overlap_kernels.hip.
+static int solve_overlapped(lpr_tableau* t, const lpr_solve_opts& o, int K, int tr, bool overlap,
+                            lpr_solve_result* res) {
+    lpr_engine* e = t->eng;
+    hipStream_t s = e->stream;
+    int rc = ov_ensure(t);
+    if (rc != LPR_OK_OPTIMAL) return rc;
+    const bool timed = o.time_kernels != 0;
+    int nlaunch = o.batch > 0 ? (o.batch + K - 1) / K : (default_batch(t) + K - 1) / K;
+    nlaunch = (nlaunch + 1) & ~1;  // even: every batch starts on control block 0
+    if (nlaunch < 2) nlaunch = 2;
+    const int64_t start_iter = t->total_pivots;
+    const int64_t max_iter = o.max_pivots > 0 ? start_iter + o.max_pivots : 0;
+    rc = ov_begin(t, start_iter, max_iter);
+    if (rc != LPR_OK_OPTIMAL) return rc;
+
+    int32_t status = kRunning, cur = 0, error = 0;
+    int64_t applied = start_iter;
+    bool first_batch = true;
+    int idle_batches = 0;
+    while (status == kRunning) {
+        int nb = nlaunch;
+        if (max_iter > 0) {  // fill + blocks + the launch that publishes the status
+            const int64_t need = (max_iter - applied) / K + 4;
+            if (need < nb) nb = (int)((need + 1) & ~1);
+        }
+        const int64_t log_before = t->log_cap;
+        const int32_t* log_ptr = t->log;
+        rc = ensure_log(t, applied + (int64_t)(nb + 1) * K + 1);
+        if (rc != LPR_OK_OPTIMAL) return rc;
+        if (t->log_cap != log_before || t->log != log_ptr) {
+            rc = ov_set_log(t, 0);
+            if (rc != LPR_OK_OPTIMAL) return rc;
+        }
+        if (timed) {
+            while ((int)t->ev.size() < 2 * nb) {
+                hipEvent_t ev;
+                LPR_HIP(hipEventCreate(&ev));
+                t->ev.push_back(ev);
+            }
+            for (int k = 0; k < nb; ++k) {
+                const bool sample = (k % kTimeStride) == 0;
+                if (!overlap) ov_launch_heads(t, K);
+                if (sample) LPR_HIP(hipEventRecord(t->ev[2 * k], s));
+                if (overlap) ov_launch_step(t, K, tr, k & 1);
+                else ov_launch_sweep(t, tr);
+                if (sample) LPR_HIP(hipEventRecord(t->ev[2 * k + 1], s));
+            }
+        } else {
+            const int gv = (overlap ? -1000 : -3000) - K * 64 - tr;  // graph key of this path
+            if (!t->graph || t->graph_batch != nb || t->graph_variant != gv) {
+                drop_graph(t);
+                hipGraph_t g = nullptr;
+                LPR_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+                for (int k = 0; k < nb; ++k) {
+                    if (overlap) {
+                        ov_launch_step(t, K, tr, k & 1);
+                    } else {
+                        ov_launch_heads(t, K);
+                        ov_launch_sweep(t, tr);
+                    }
+                }
+                LPR_HIP(hipStreamEndCapture(s, &g));
+                hipError_t ierr = hipGraphInstantiate(&t->graph, g, nullptr, nullptr, 0);
+                hipGraphDestroy(g);
+                if (ierr != hipSuccess) {
+                    t->graph = nullptr;
+                    set_error("hipGraphInstantiate failed: %s", hipGetErrorString(ierr));
+                    return LPR_DEVICE_ERROR;
+                }
+                t->graph_batch = nb;
+                t->graph_variant = gv;
+            }
+            LPR_HIP(hipGraphLaunch(t->graph, s));
+        }
+        LPR_HIP(hipGetLastError());
+        int64_t now = applied;
+        rc = ov_poll(t, 0, &status, &cur, &now, &error);
+        if (rc != LPR_OK_OPTIMAL) return rc;
+        if (error || status == LPR_DEVICE_ERROR) {
+            set_error("overlapped pivot loop: a grid barrier of the loop heads timed out");
+            return LPR_DEVICE_ERROR;
+        }
+        if (timed) {
+            // launches sweep full blocks (K pivots) in order: first the pipeline fill (the very
+            // first launch of the call sweeps nothing), then full blocks until the solve ends
+            const int64_t swept = (now - applied) / K;
+            const int first = (first_batch && overlap) ? 1 : 0;
+            for (int k = 0; k < nb; k += kTimeStride) {
+                if (k < first || k >= first + swept) continue;
+                float ms = 0.f;
+                LPR_HIP(hipEventElapsedTime(&ms, t->ev[2 * k], t->ev[2 * k + 1]));
+                t->timed_total_ms += ms;
+                t->timed_launches += 1;
+            }
+        }
+        idle_batches = (now == applied) ? idle_batches + 1 : 0;
+        applied = now;
+        first_batch = false;
+        if (status == kRunning && idle_batches >= 3) {
+            set_error("overlapped pivot loop made no progress (device status still running)");
+            return LPR_DEVICE_ERROR;
+        }
+    }
+    drop_graph(t);  // the captured launches hold the buffer pointers of this call
+    ov_adopt_buffer(t, cur);
+    t->total_pivots = applied;
+    res->status = status;
+    res->block = K;
+    res->pivots = applied - start_iter;
+    res->total_pivots = applied;
     double z = 0.0;
     LPR_HIP(hipMemcpyAsync(&z, t->T + (t->cols - 1), sizeof(double), hipMemcpyDeviceToHost, s));
     LPR_HIP(hipStreamSynchronize(s));
@@ -658,8 +793,16 @@ int lpr_primal_solve(lpr_tableau* t, const lpr_solve_opts* opts, lpr_solve_resul
 
     if (use_fused(t, o)) return solve_fused(t, o, res);
     {
+        // variant 0x60tr: in-place blocked path; 0x50tr or none: the overlapped path
         const int K = block_size(t, o);
-        if (K > 1) return solve_blocked(t, o, K, res);
+        if (K > 1 && (o.variant & 0xff00) == 0x6000) return solve_blocked(t, o, K, res);
+        // 0x50tr: sweep out of place with the next block's heads inside the same launch;
+        // default / 0x40tr: all heads of a block in one persistent launch, then the sweep in place
+        if (K > 1) {
+            const bool overlap = (o.variant & 0xff00) == 0x5000;
+            const int tr = (o.variant & 0xff00) ? (o.variant & 0xff) : 8;
+            return solve_overlapped(t, o, K, tr, overlap, res);
+        }
     }
     const int variant = (o.variant > 0 && o.variant < 0x7000) ? o.variant - 1 : default_variant(t);
     int batch = o.batch > 0 ? o.batch : default_batch(t);

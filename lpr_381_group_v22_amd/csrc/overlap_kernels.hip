@@ -1,0 +1,751 @@
+// overlap_kernels.hip -- the large-tableau primal path: K pivots per sweep, with the decisions for
+// the NEXT K pivots made while the sweep of the current K is running.
+// (reference: LPR_381_Group_V22/Simplex/PrimalSimplexSolver.cs:102-211)
+//
+// block_kernels.hip explains why K pivots can be decided from O(R + C) data each and then applied
+// to every element in one sweep with bit-identical results.  Here the sweep is out of place
+// (tableau buffer `cur` -> buffer `cur ^ 1`), so while it runs, the buffer it reads is still the
+// tableau BEFORE the block -- and the loop heads of the next block can work from that very
+// buffer, taking every column / row they fetch through the block being swept plus their own
+// earlier pivots.  One launch of k_ov_step therefore contains
+//   * workgroups [0, G): the heads of block B+1, a persistent loop over its pivots with a
+//     spin barrier between the phases (gather the entering column | ratio test, normalise the
+//     row, next Z row).  They are dispatched first, so all G are resident when they meet.
+//   * the remaining workgroups: the sweep of block B, TR x 256-double2 tiles.
+// and a launch lasts max(sweep, heads).  Per pivot the tableau moves 2*8*R*C / K bytes.
+//
+// Control state that a launch both reads and updates exists twice (`OvCtl ctl[2]`): the launch
+// with parity p reads ctl[p] and its two lead workgroups write ctl[p ^ 1] -- so no workgroup can
+// see a field change under it.  Same for the barrier counter.
+#include "engine_common.hpp"
+#include "select_common.hpp"
+
+#include <cstdlib>
+#include <new>
+
+#pragma clang fp contract(off)
+
+namespace lpr {
+
+constexpr int kOvMax = 16;      // pivots per block, upper bound
+constexpr int kOvNT = 256;      // threads per workgroup (heads and tiles)
+constexpr int kOvGroups = 64;   // head workgroups, upper bound
+constexpr unsigned kOvSpinMax = 1u << 22;
+constexpr int kOvTileRows = 32; // rows per sweep workgroup (TR of them in flight at a time)
+constexpr int kOvU = 17;        // dense-vector elements a lane keeps in flight (17 * 256 >= 4097)
+
+struct OvCtl {
+    int32_t status;    // kRunning or the final lpr_status
+    int32_t pending;   // kRunning, or the status that ends the solve once the staged block is swept
+    int32_t kdone;     // pivots of the block the reader's tiles must apply
+    int32_t slot;      // staging slot holding that block (the heads stage into slot ^ 1)
+    int32_t cur;       // buffer holding the tableau before that block
+    int32_t sweep;     // parity of the sweep direction
+    int32_t r[kOvMax]; // pivot rows of that block
+    int32_t error;     // a grid barrier timed out
+    int32_t pad;
+    int64_t staged;    // pivots decided so far (index of the next one)
+    int64_t applied;   // pivots swept into the tableau so far
+    int64_t max_iter;  // <= 0: no limit
+    int64_t log_cap;
+    int64_t dbg[8];    // DIAG
+    int64_t tdbg[4];   // DIAG
+};
+
+struct OvBuffers {      // everything the step kernel touches, passed by value
+    double* Tb[2];      // the two tableau buffers
+    double* prow;       // [2][kOvMax][ld]  normalised pivot rows per staging slot
+    double* fcol;       // [2][kOvMax][Rp]  factor columns per staging slot
+    double* zrow;       // [ld]  Z row of the tableau after all staged pivots
+    double* bvec;       // [2][Rp] RHS column after `staged` pivots in bvec[staged & 1]
+    ZPart* zparts;      // [2][kOvGroups]
+    OvCtl* ctl;         // [2]
+    unsigned* bar;      // [2]
+    int32_t* basis;
+    int32_t* log;
+};
+
+// ------------------------------------------------------------------------------------------
+// Per solve call: Z row, RHS column and entering column of the tableau in memory.
+__global__ __launch_bounds__(1024) void k_ov_prologue(const double* __restrict__ T, int ld, int R,
+                                                      int C, double* __restrict__ zrow,
+                                                      double* __restrict__ bvec0,
+                                                      ZPart* __restrict__ bank, int G) {
+    __shared__ double lds_v[16];
+    __shared__ int lds_i[16];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    Cand c;
+    c.v = 0.0;
+    c.i = -1;
+    for (int j = tid; j < ld; j += nt) {
+        const double v = T[j];
+        zrow[j] = v;
+        if (j < C - 1 && v < c.v) {
+            c.v = v;
+            c.i = j;
+        }
+    }
+    c = block_cand_min(c, lds_v, lds_i);
+    if (tid < G) {
+        bank[tid].v = (tid == 0) ? c.v : 0.0;
+        bank[tid].i = (tid == 0) ? c.i : -1;
+    }
+    for (int i = tid; i < R; i += nt) bvec0[i] = T[(size_t)i * ld + (C - 1)];
+}
+
+// arg-min over the G partials, one per lane (G <= 64), every wave on its own
+__device__ __forceinline__ Cand ov_reduce_zparts(const ZPart* bank, int G) {
+    const int lane = threadIdx.x & (kWave - 1);
+    Cand c;
+    c.v = 0.0;
+    c.i = -1;
+    if (lane < G) {
+        c.v = bank[lane].v;
+        c.i = bank[lane].i;
+    }
+    return wave_cand_min(c);
+}
+
+// Barrier over the G head workgroups.  Returns false when it timed out.
+__device__ __forceinline__ bool ov_barrier(unsigned* bar, unsigned target) {
+    __shared__ int ok;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();  // release: this workgroup's writes are visible before it arrives
+        atomicAdd(bar, 1u);
+        unsigned spins = 0;
+        int good = 1;
+        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > kOvSpinMax) {
+                good = 0;
+                break;
+            }
+        }
+        ok = good;
+    }
+    __syncthreads();
+    __threadfence();  // acquire: drop this CU's stale lines before reading the others' results
+    return ok != 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// The heads of the next block (workgroups [0, G)).
+__device__ void ov_heads(const OvBuffers B, int ld, int R, int C, int Rp, int K, int G, int lp,
+                         bool solo) {
+    __shared__ double lds_v[16];
+    __shared__ int lds_i[16];
+    __shared__ double lds_p[2];
+    __shared__ int s_r[kOvMax];   // rows of the pivots staged by this launch
+    __shared__ int rA[kOvMax];    // rows of the pivots of the block being swept
+    __shared__ double s_fa[kOvMax], s_fn[kOvMax];  // f_t[r] of the earlier pivots
+    __shared__ double s_pa[kOvMax], s_pn[kOvMax];  // p_t[e], later p_t[rhs]
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int g = blockIdx.x;
+    const bool lead = (g == 0);
+    const OvCtl* ci = B.ctl + lp;
+    OvCtl* co = B.ctl + (lp ^ 1);
+    const int32_t status = ci->status;
+    const int32_t pend_in = ci->pending;
+    const int kb = solo ? 0 : ci->kdone;  // pivots of the block being swept right now
+    const int sa = ci->slot;        // ... staged in this slot
+    const int64_t staged0 = ci->staged;
+    const int64_t mx = ci->max_iter;
+    const int64_t log_cap = ci->log_cap;
+    const double* __restrict__ Tin = B.Tb[ci->cur];
+    const int ld2 = ld >> 1;
+    const int rhs = C - 1;
+    const size_t slotP = (size_t)kOvMax * ld, slotF = (size_t)kOvMax * Rp;
+    // not __restrict__: other head workgroups write these between the barriers
+    double* prowA = B.prow + (size_t)sa * slotP;
+    double* fcolA = B.fcol + (size_t)sa * slotF;
+    double* prowN = B.prow + (size_t)(sa ^ 1) * slotP;
+    double* fcolN = B.fcol + (size_t)(sa ^ 1) * slotF;
+    double* zrow = B.zrow;
+    unsigned* bar = B.bar + lp;
+    if (tid < kOvMax) rA[tid] = (tid < kb) ? ci->r[tid] : -1;
+    __syncthreads();
+
+    int32_t pend_out = pend_in;
+    int32_t status_out = status;
+    int count = 0;
+    int err = 0;
+    unsigned nbar = 0;
+    int64_t dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // DIAG
+    const int64_t TS = wall_clock64();  // DIAG
+
+    if (status == kRunning && pend_in != kRunning) {
+        status_out = pend_in;  // the block staged before is being swept by this very launch
+    } else if (status == kRunning) {
+        for (int q = 1; q <= K; ++q) {
+            const int64_t T0 = wall_clock64();  // DIAG
+            const int64_t pidx = staged0 + q - 1;
+            const ZPart* bank_in = B.zparts + (pidx & 1) * kOvGroups;
+            ZPart* bank_out = B.zparts + ((pidx + 1) & 1) * kOvGroups;
+            const double* bprev = B.bvec + (size_t)(pidx & 1) * Rp;
+            double* bnew = B.bvec + (size_t)((pidx + 1) & 1) * Rp;
+            double* colq = fcolN + (size_t)(q - 1) * Rp;
+
+            // ---- entering column (:152-167) from the partials of the previous head ----
+            const int e = ov_reduce_zparts(bank_in, G).i;
+            if (e < 0) {
+                pend_out = LPR_OK_OPTIMAL;
+                break;
+            }
+            const int64_t T1 = wall_clock64();  // DIAG
+            // ---- column e of the tableau after all earlier pivots, this workgroup's rows ----
+            if (tid < kb) s_pa[tid] = prowA[(size_t)tid * ld + e];
+            if (tid >= 32 && tid - 32 < q - 1) s_pn[tid - 32] = prowN[(size_t)(tid - 32) * ld + e];
+            __syncthreads();
+            for (int i = g * nt + tid; i < R; i += G * nt) {
+                double c = Tin[(size_t)i * ld + e];
+                for (int t0 = 0; t0 < kb; t0 += 8) {  // through the block being swept
+                    double f[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        f[u] = (t0 + u < kb) ? fcolA[(size_t)(t0 + u) * Rp + i] : 0.0;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int t = t0 + u;
+                        if (t < kb) {
+                            if (i == rA[t]) {
+                                c = s_pa[t];
+                            } else {
+                                const double prod = f[u] * s_pa[t];
+                                c = c - prod;
+                            }
+                        }
+                    }
+                }
+                for (int t0 = 0; t0 < q - 1; t0 += 8) {  // through this block's earlier pivots
+                    double f[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        f[u] = (t0 + u < q - 1) ? fcolN[(size_t)(t0 + u) * Rp + i] : 0.0;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int t = t0 + u;
+                        if (t < q - 1) {
+                            if (i == s_r[t]) {
+                                c = s_pn[t];
+                            } else {
+                                const double prod = f[u] * s_pn[t];
+                                c = c - prod;
+                            }
+                        }
+                    }
+                }
+                colq[i] = c;
+            }
+            const int64_t T2 = wall_clock64();  // DIAG
+            if (!ov_barrier(bar, (++nbar) * (unsigned)G)) {
+                err = 1;
+                break;
+            }
+            const int64_t T3 = wall_clock64();  // DIAG
+
+            // ---- FindLeavingVariable (:169-191) on the dense column / RHS ----
+            Cand c;
+            c.v = DBL_MAX;
+            c.i = -1;
+            double a_of_best = 0.0;
+            for (int i0 = tid; i0 < R; i0 += kOvU * nt) {
+                double a[kOvU], b[kOvU];
+#pragma unroll
+                for (int u = 0; u < kOvU; ++u) {
+                    const int i = i0 + u * nt;
+                    a[u] = (i < R) ? colq[i] : 0.0;
+                    b[u] = (i < R) ? bprev[i] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < kOvU; ++u) {
+                    const int i = i0 + u * nt;
+                    if (i < R) {
+                        if (i == 0) lds_p[1] = a[u];
+                        if (i >= 1 && a[u] > 1e-9) {
+                            const double ratio = b[u] / a[u];
+                            if (ratio >= 0 && ratio < c.v) {
+                                c.v = ratio;
+                                c.i = i;
+                                a_of_best = a[u];
+                            }
+                        }
+                    }
+                }
+            }
+            const int my_best = c.i;
+            c = block_cand_min(c, lds_v, lds_i);
+            const int r = c.i;
+            if (r < 0) {
+                pend_out = LPR_UNBOUNDED;
+                break;
+            }
+            if (mx > 0 && pidx >= mx) {
+                pend_out = LPR_PIVOT_LIMIT;
+                break;
+            }
+            if (my_best == r) lds_p[0] = a_of_best;
+            if (tid == 0) s_r[q - 1] = r;
+            __syncthreads();
+            const int64_t T4 = wall_clock64();  // DIAG
+            const double p = lds_p[0];
+            const double f0 = lds_p[1];
+
+            // ---- row r after all earlier pivots, normalised (:199); next Z row; partial ----
+            // f_t[r] of every earlier pivot, once per workgroup
+            if (tid < kb) s_fa[tid] = fcolA[(size_t)tid * Rp + r];
+            if (tid >= 32 && tid - 32 < q - 1) s_fn[tid - 32] = fcolN[(size_t)(tid - 32) * Rp + r];
+            if (tid >= 64 && tid - 64 < kb) s_pa[tid - 64] = prowA[(size_t)(tid - 64) * ld + rhs];
+            if (tid >= 96 && tid - 96 < q - 1) s_pn[tid - 96] = prowN[(size_t)(tid - 96) * ld + rhs];
+            double wr = (tid == 128) ? Tin[(size_t)r * ld + rhs] : 0.0;
+            __syncthreads();
+            const double2* Tin2 = reinterpret_cast<const double2*>(Tin);
+            const double2* prowA2 = reinterpret_cast<const double2*>(prowA);
+            double2* prowN2 = reinterpret_cast<double2*>(prowN);
+            double2* zrow2 = reinterpret_cast<double2*>(zrow);
+            Cand n;
+            n.v = 0.0;
+            n.i = -1;
+            for (int c2 = g * nt + tid; c2 < ld2; c2 += G * nt) {
+                double2 w = Tin2[(size_t)r * ld2 + c2];
+                double2 z = zrow2[c2];
+                for (int t0 = 0; t0 < kb; t0 += 8) {
+                    double2 ps[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        ps[u] = (t0 + u < kb) ? prowA2[(size_t)(t0 + u) * ld2 + c2]
+                                              : make_double2(0.0, 0.0);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int t = t0 + u;
+                        if (t < kb) {
+                            if (r == rA[t]) {
+                                w = ps[u];
+                            } else {
+                                const double f = s_fa[t];
+                                const double px = f * ps[u].x;
+                                const double py = f * ps[u].y;
+                                w.x = w.x - px;
+                                w.y = w.y - py;
+                            }
+                        }
+                    }
+                }
+                for (int t0 = 0; t0 < q - 1; t0 += 8) {
+                    double2 ps[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        ps[u] = (t0 + u < q - 1) ? prowN2[(size_t)(t0 + u) * ld2 + c2]
+                                                 : make_double2(0.0, 0.0);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int t = t0 + u;
+                        if (t < q - 1) {
+                            if (r == s_r[t]) {
+                                w = ps[u];
+                            } else {
+                                const double f = s_fn[t];
+                                const double px = f * ps[u].x;
+                                const double py = f * ps[u].y;
+                                w.x = w.x - px;
+                                w.y = w.y - py;
+                            }
+                        }
+                    }
+                }
+                const int j = 2 * c2;
+                double2 pq;
+                pq.x = (j < C) ? w.x / p : 0.0;  // :199 true division
+                pq.y = (j + 1 < C) ? w.y / p : 0.0;
+                prowN2[(size_t)(q - 1) * ld2 + c2] = pq;
+                const double mxp = f0 * pq.x;  // :208 product rounded, then the difference
+                const double myp = f0 * pq.y;
+                z.x = z.x - mxp;
+                z.y = z.y - myp;
+                zrow2[c2] = z;
+                if (j < C - 1 && z.x < n.v) {
+                    n.v = z.x;
+                    n.i = j;
+                }
+                if (j + 1 < C - 1 && z.y < n.v) {
+                    n.v = z.y;
+                    n.i = j + 1;
+                }
+            }
+            n = block_cand_min(n, lds_v, lds_i);
+
+            // ---- RHS column after this pivot ----
+            if (tid == 128) {
+                for (int t = 0; t < kb; ++t) {
+                    if (r == rA[t]) {
+                        wr = s_pa[t];
+                    } else {
+                        const double prod = s_fa[t] * s_pa[t];
+                        wr = wr - prod;
+                    }
+                }
+                for (int t = 0; t < q - 1; ++t) {
+                    if (r == s_r[t]) {
+                        wr = s_pn[t];
+                    } else {
+                        const double prod = s_fn[t] * s_pn[t];
+                        wr = wr - prod;
+                    }
+                }
+                lds_p[0] = wr / p;  // p was read by every lane before the arg-min barriers above
+            }
+            __syncthreads();
+            const double prhs = lds_p[0];
+            for (int i = g * nt + tid; i < R; i += G * nt) {
+                const double prod = colq[i] * prhs;
+                bnew[i] = (i == r) ? prhs : bprev[i] - prod;
+            }
+            if (tid == 0) {
+                bank_out[g].v = n.v;
+                bank_out[g].i = n.i;
+                if (lead) {
+                    co->r[q - 1] = r;
+                    B.basis[r - 1] = e;  // :142
+                    if (pidx < log_cap) {
+                        B.log[2 * pidx] = r;
+                        B.log[2 * pidx + 1] = e;
+                    }
+                }
+            }
+            count = q;
+            const int64_t T5 = wall_clock64();  // DIAG
+            dbg[0] += T1 - T0; dbg[1] += T2 - T1; dbg[2] += T3 - T2; dbg[3] += T4 - T3; dbg[4] += T5 - T4;  // DIAG
+            if (!ov_barrier(bar, (++nbar) * (unsigned)G)) {
+                err = 1;
+                break;
+            }
+        }
+    }
+
+    if (lead && tid == 0) {  // the next launch's view (fields owned by the heads)
+        const bool staged_now = (status == kRunning && pend_in == kRunning);
+        co->status = err ? LPR_DEVICE_ERROR : status_out;
+        co->pending = pend_out;
+        co->kdone = staged_now ? count : 0;
+        co->slot = staged_now ? (sa ^ 1) : sa;
+        co->staged = staged0 + (staged_now ? count : 0);
+        co->max_iter = mx;
+        co->log_cap = log_cap;
+        co->error = err | ci->error;
+        dbg[5] = wall_clock64() - TS; dbg[6] = count; dbg[7] = TS;  // DIAG
+        for (int k = 0; k < 8; ++k) co->dbg[k] = dbg[k];  // DIAG
+        B.bar[lp ^ 1] = 0u;  // nobody touches the other counter during this launch
+        if (solo) {  // no sweep in this launch: its fields are carried over here
+            co->applied = ci->applied;
+            co->cur = ci->cur;
+            co->sweep = ci->sweep;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// The sweep of the current block (workgroups [G, ...)): every element through kdone pivots
+// (:202-210 each) in registers, buffer cur -> buffer cur ^ 1.
+template <int TR, bool INPLACE>
+__device__ void ov_tiles(const OvBuffers B, int ld, int R, int Rp, int G, int lp) {
+    const OvCtl* ci = B.ctl + lp;
+    const int tb = blockIdx.x - G;
+    const int K = (ci->status == kRunning) ? ci->kdone : 0;
+    const int cur = ci->cur;
+    if (tb == 0 && threadIdx.x == 0) {  // the next launch's view (fields owned by the sweep)
+        OvCtl* co = B.ctl + (lp ^ 1);
+        co->applied = ci->applied + K;
+        co->cur = (K > 0 && !INPLACE) ? (cur ^ 1) : cur;
+        co->sweep = ci->sweep ^ 1;
+        if (INPLACE) {  // no heads in this launch: their fields are carried over here
+            co->status = ci->status;
+            co->pending = ci->pending;
+            co->kdone = 0;
+            co->slot = ci->slot;
+            co->staged = ci->staged;
+            co->max_iter = ci->max_iter;
+            co->log_cap = ci->log_cap;
+            co->error = ci->error;
+            B.bar[lp ^ 1] = 0u;
+        }
+    }
+    if (K <= 0) return;
+    const int ld2 = ld >> 1;
+    const int nct = (ld2 + kOvNT - 1) / kOvNT;
+    const int nrt = (R + kOvTileRows - 1) / kOvTileRows;
+    int ct = tb % nct, rt = tb / nct;
+    if (rt >= nrt) return;
+    if (ci->sweep & 1) {
+        ct = nct - 1 - ct;
+        rt = nrt - 1 - rt;
+    }
+    const int c2 = ct * kOvNT + threadIdx.x;
+    // the factors f_s[i] of this tile's rows go through LDS: a broadcast read per (row, pivot)
+    // instead of a global load the compiler must order against the tile's own stores
+    __shared__ double s_f[kOvMax * kOvTileRows];
+    {
+        const double* fc = B.fcol + (size_t)ci->slot * kOvMax * Rp;
+        const int ibase = rt * kOvTileRows;
+        for (int idx = threadIdx.x; idx < K * kOvTileRows; idx += kOvNT) {
+            const int sidx = idx / kOvTileRows, j = idx % kOvTileRows;
+            s_f[idx] = (ibase + j < R) ? fc[(size_t)sidx * Rp + ibase + j] : 0.0;
+        }
+    }
+    __syncthreads();
+    if (c2 >= ld2) return;
+    // in place every element is read and written by the same lane; out of place the buffers differ
+    const double2* Tin2 = reinterpret_cast<const double2*>(B.Tb[cur]);
+    double2* Tout2 = reinterpret_cast<double2*>(B.Tb[INPLACE ? cur : (cur ^ 1)]);
+    const int sa = ci->slot;
+    const double2* __restrict__ prow2 =
+        reinterpret_cast<const double2*>(B.prow + (size_t)sa * kOvMax * ld);
+    int rr[kOvMax];
+    double2 p[kOvMax];  // this lane's slice of the K normalised pivot rows, for the whole tile
+#pragma unroll
+    for (int s = 0; s < kOvMax; ++s) {
+        rr[s] = (s < K) ? ci->r[s] : -1;
+        p[s] = (s < K) ? prow2[(size_t)s * ld2 + c2] : make_double2(0.0, 0.0);
+    }
+    const int iend = min(R, (rt + 1) * kOvTileRows);
+    for (int i0 = rt * kOvTileRows; i0 < iend; i0 += TR) {  // TR rows in flight per lane
+        double2 x[TR];
+#pragma unroll
+        for (int k = 0; k < TR; ++k) {
+            const int i = i0 + k;
+            if (i < iend) x[k] = Tin2[(size_t)i * ld2 + c2];
+        }
+#pragma unroll
+        for (int k = 0; k < TR; ++k) {
+            const int i = i0 + k;
+            if (i < iend) {
+                double2 t = x[k];
+#pragma unroll
+                for (int s = 0; s < kOvMax; ++s) {
+                    if (s < K) {
+                        if (i == rr[s]) {
+                            t = p[s];  // the pivot row keeps the normalised values (:199)
+                        } else {
+                            const double f = s_f[s * kOvTileRows + (i - rt * kOvTileRows)];
+                            const double px = f * p[s].x;  // product rounded ...
+                            const double py = f * p[s].y;
+                            t.x = t.x - px;                // ... then the difference (:208)
+                            t.y = t.y - py;
+                        }
+                    }
+                }
+                Tout2[(size_t)i * ld2 + c2] = t;
+            }
+        }
+    }
+}
+
+template <int TR>
+__global__ __launch_bounds__(kOvNT) void k_ov_step(const OvBuffers B, int ld, int R, int C, int Rp,
+                                                   int K, int G, int lp) {
+    if ((int)blockIdx.x < G)
+        ov_heads(B, ld, R, C, Rp, K, G, lp, false);
+    else
+        ov_tiles<TR, false>(B, ld, R, Rp, G, lp);
+}
+
+// The same two halves as separate launches: all K loop heads of a block in ONE persistent launch
+// (no sweep running: nothing to chain through but the block's own pivots), then the sweep in
+// place.  Heads always run on control block 0, the sweep on control block 1.
+__global__ __launch_bounds__(kOvNT) void k_ov_heads(const OvBuffers B, int ld, int R, int C, int Rp,
+                                                    int K, int G) {
+    ov_heads(B, ld, R, C, Rp, K, G, 0, true);
+}
+
+template <int TR>
+__global__ __launch_bounds__(kOvNT) void k_ov_sweep(const OvBuffers B, int ld, int R, int Rp) {
+    ov_tiles<TR, true>(B, ld, R, Rp, 0, 1);
+}
+
+}  // namespace lpr
+
+// ---------------------------------------------------------------------------------------------
+// host side (the driver loop lives in lpr_engine.hip)
+
+struct lpr_overlap_ctx {
+    int rows = 0, ld = 0, Rp = 0;
+    lpr::OvBuffers b{};
+    lpr::OvCtl* h_ctl = nullptr;  // pinned, 2 entries
+    double* T2 = nullptr;         // the second tableau buffer (owned here)
+};
+
+namespace lpr {
+
+int ov_max_pivots() { return kOvMax; }
+
+void ov_release(lpr_tableau* t) {
+    lpr_overlap_ctx* c = static_cast<lpr_overlap_ctx*>(t->ov);
+    if (!c) return;
+    hipFree(c->T2);
+    hipFree(c->b.prow);
+    hipFree(c->b.fcol);
+    hipFree(c->b.zrow);
+    hipFree(c->b.bvec);
+    hipFree(c->b.zparts);
+    hipFree(c->b.ctl);
+    hipFree(c->b.bar);
+    if (c->h_ctl) hipHostFree(c->h_ctl);
+    delete c;
+    t->ov = nullptr;
+}
+
+int ov_ensure(lpr_tableau* t) {
+    lpr_overlap_ctx* c = static_cast<lpr_overlap_ctx*>(t->ov);
+    if (c && c->rows == t->rows && c->ld == t->ld) return LPR_OK_OPTIMAL;
+    ov_release(t);
+    c = new (std::nothrow) lpr_overlap_ctx();
+    if (!c) return LPR_OUT_OF_MEMORY;
+    c->rows = t->rows;
+    c->ld = t->ld;
+    c->Rp = align_up(t->rows, 16);
+    hipError_t err = hipSuccess;
+    auto chk = [&](hipError_t x) { if (err == hipSuccess) err = x; };
+    const size_t D = sizeof(double);
+    const size_t tbytes = (size_t)t->rows * t->ld * D;
+    chk(hipMalloc(&c->T2, tbytes));
+    chk(hipMalloc(&c->b.prow, (size_t)2 * kOvMax * c->ld * D));
+    chk(hipMalloc(&c->b.fcol, (size_t)2 * kOvMax * c->Rp * D));
+    chk(hipMalloc(&c->b.zrow, (size_t)c->ld * D));
+    chk(hipMalloc(&c->b.bvec, (size_t)2 * c->Rp * D));
+    chk(hipMalloc(&c->b.zparts, (size_t)2 * kOvGroups * sizeof(ZPart)));
+    chk(hipMalloc(&c->b.ctl, 2 * sizeof(OvCtl)));
+    chk(hipMalloc(&c->b.bar, 2 * sizeof(unsigned)));
+    chk(hipHostMalloc(&c->h_ctl, 2 * sizeof(OvCtl)));
+    t->ov = c;
+    if (err != hipSuccess) {
+        set_error("overlapped-pivot scratch allocation failed: %s", hipGetErrorString(err));
+        ov_release(t);
+        return err == hipErrorOutOfMemory ? LPR_OUT_OF_MEMORY : LPR_DEVICE_ERROR;
+    }
+    hipStream_t s = t->eng->stream;
+    LPR_HIP(hipMemsetAsync(c->T2, 0, tbytes, s));
+    LPR_HIP(hipMemsetAsync(c->b.prow, 0, (size_t)2 * kOvMax * c->ld * D, s));
+    LPR_HIP(hipMemsetAsync(c->b.fcol, 0, (size_t)2 * kOvMax * c->Rp * D, s));
+    LPR_HIP(hipMemsetAsync(c->b.zrow, 0, (size_t)c->ld * D, s));
+    LPR_HIP(hipMemsetAsync(c->b.bvec, 0, (size_t)2 * c->Rp * D, s));
+    LPR_HIP(hipMemsetAsync(c->b.zparts, 0, (size_t)2 * kOvGroups * sizeof(ZPart), s));
+    std::memset(c->h_ctl, 0, 2 * sizeof(OvCtl));
+    return LPR_OK_OPTIMAL;
+}
+
+static int ov_groups(const lpr_tableau* t) {
+    int g = (t->ld / 2 + kOvNT - 1) / kOvNT;
+    if (g < 1) g = 1;
+    if (g > kOvGroups) g = kOvGroups;
+    return g;
+}
+
+// start of a solve call: control block 0, barrier counters, Z row / RHS column / entering column
+int ov_begin(lpr_tableau* t, int64_t iter, int64_t max_iter) {
+    lpr_overlap_ctx* c = static_cast<lpr_overlap_ctx*>(t->ov);
+    hipStream_t s = t->eng->stream;
+    c->b.Tb[0] = t->T;
+    c->b.Tb[1] = c->T2;
+    c->b.basis = t->basis;
+    c->b.log = t->log;
+    OvCtl* h = c->h_ctl;
+    std::memset(h, 0, 2 * sizeof(OvCtl));
+    h[0].status = kRunning;
+    h[0].pending = kRunning;
+    h[0].staged = iter;
+    h[0].applied = iter;
+    h[0].max_iter = max_iter;
+    h[0].log_cap = t->log_cap;
+    h[1] = h[0];
+    LPR_HIP(hipMemcpyAsync(c->b.ctl, h, 2 * sizeof(OvCtl), hipMemcpyHostToDevice, s));
+    LPR_HIP(hipMemsetAsync(c->b.bar, 0, 2 * sizeof(unsigned), s));
+    hipLaunchKernelGGL(k_ov_prologue, dim3(1), dim3(1024), 0, s, t->T, t->ld, t->rows, t->cols,
+                       c->b.zrow, c->b.bvec + (size_t)(iter & 1) * c->Rp,
+                       c->b.zparts + (iter & 1) * kOvGroups, ov_groups(t));
+    LPR_HIP(hipGetLastError());
+    return LPR_OK_OPTIMAL;
+}
+
+// the log buffer was re-allocated: new pointer / capacity for the following launches
+int ov_set_log(lpr_tableau* t, int parity) {
+    lpr_overlap_ctx* c = static_cast<lpr_overlap_ctx*>(t->ov);
+    c->b.log = t->log;
+    c->h_ctl[0].log_cap = t->log_cap;
+    LPR_HIP(hipMemcpyAsync(&c->b.ctl[parity].log_cap, &c->h_ctl[0].log_cap, sizeof(int64_t),
+                           hipMemcpyHostToDevice, t->eng->stream));
+    return LPR_OK_OPTIMAL;
+}
+
+void ov_launch_step(lpr_tableau* t, int K, int tr, int lp) {
+    lpr_overlap_ctx* c = static_cast<lpr_overlap_ctx*>(t->ov);
+    hipStream_t s = t->eng->stream;
+    const int G = ov_groups(t);
+    const int ld2 = t->ld / 2;
+    const int nct = (ld2 + kOvNT - 1) / kOvNT;
+    const int nrt = (t->rows + kOvTileRows - 1) / kOvTileRows;
+    if (tr >= 16)
+        hipLaunchKernelGGL((k_ov_step<16>), dim3(G + nct * nrt), dim3(kOvNT), 0, s, c->b, t->ld,
+                           t->rows, t->cols, c->Rp, K, G, lp);
+    else if (tr >= 8)
+        hipLaunchKernelGGL((k_ov_step<8>), dim3(G + nct * nrt), dim3(kOvNT), 0, s, c->b, t->ld,
+                           t->rows, t->cols, c->Rp, K, G, lp);
+    else
+        hipLaunchKernelGGL((k_ov_step<4>), dim3(G + nct * nrt), dim3(kOvNT), 0, s, c->b, t->ld,
+                           t->rows, t->cols, c->Rp, K, G, lp);
+}
+
+void ov_launch_heads(lpr_tableau* t, int K) {
+    lpr_overlap_ctx* c = static_cast<lpr_overlap_ctx*>(t->ov);
+    const int G = ov_groups(t);
+    hipLaunchKernelGGL(k_ov_heads, dim3(G), dim3(kOvNT), 0, t->eng->stream, c->b, t->ld, t->rows,
+                       t->cols, c->Rp, K, G);
+}
+
+void ov_launch_sweep(lpr_tableau* t, int tr) {
+    lpr_overlap_ctx* c = static_cast<lpr_overlap_ctx*>(t->ov);
+    hipStream_t s = t->eng->stream;
+    const int nct = (t->ld / 2 + kOvNT - 1) / kOvNT;
+    const int nrt = (t->rows + kOvTileRows - 1) / kOvTileRows;
+    if (tr >= 16)
+        hipLaunchKernelGGL((k_ov_sweep<16>), dim3(nct * nrt), dim3(kOvNT), 0, s, c->b, t->ld,
+                           t->rows, c->Rp);
+    else if (tr >= 8)
+        hipLaunchKernelGGL((k_ov_sweep<8>), dim3(nct * nrt), dim3(kOvNT), 0, s, c->b, t->ld,
+                           t->rows, c->Rp);
+    else
+        hipLaunchKernelGGL((k_ov_sweep<4>), dim3(nct * nrt), dim3(kOvNT), 0, s, c->b, t->ld,
+                           t->rows, c->Rp);
+}
+
+// reads control block `parity` back
+int ov_poll(lpr_tableau* t, int parity, int32_t* status, int32_t* cur, int64_t* applied,
+            int32_t* error) {
+    lpr_overlap_ctx* c = static_cast<lpr_overlap_ctx*>(t->ov);
+    hipStream_t s = t->eng->stream;
+    LPR_HIP(hipMemcpyAsync(c->h_ctl, c->b.ctl, 2 * sizeof(OvCtl), hipMemcpyDeviceToHost, s));
+    LPR_HIP(hipStreamSynchronize(s));
+    *status = c->h_ctl[parity].status;
+    *cur = c->h_ctl[parity].cur;
+    *applied = c->h_ctl[parity].applied;
+    *error = c->h_ctl[parity].error;
+    if (getenv("LPR_OV_DIAG")) {  // DIAG
+        const int64_t* d = c->h_ctl[parity].dbg;
+        fprintf(stderr, "[ov diag x10ns] zparts %lld gather %lld bar1 %lld ratio %lld row %lld | heads total %lld pivots %lld\n",
+                (long long)d[0], (long long)d[1], (long long)d[2], (long long)d[3], (long long)d[4], (long long)d[5], (long long)d[6]);
+        const int64_t* td = c->h_ctl[parity].tdbg;
+        fprintf(stderr, "[ov diag2 x10ns rel. to heads start] first tile %lld..%lld last tile %lld..%lld\n",
+                (long long)(td[0] - d[7]), (long long)(td[1] - d[7]), (long long)(td[2] - d[7]), (long long)(td[3] - d[7]));
+    }
+    return LPR_OK_OPTIMAL;
+}
+
+// end of a solve call: the live tableau must be t->T
+void ov_adopt_buffer(lpr_tableau* t, int cur) {
+    lpr_overlap_ctx* c = static_cast<lpr_overlap_ctx*>(t->ov);
+    if (cur == 1) {  // the result is in the second buffer: swap ownership
+        double* tmp = t->T;
+        t->T = c->T2;
+        c->T2 = tmp;
+    }
+}
+
+}  // namespace lpr

@@ -1,7 +1,11 @@
-"""GPU parity tests of the K-pivots-per-sweep path (csrc/block_kernels.hip, opts.block): deciding
-K pivots ahead from O(R + C) data and applying them in one sweep must give the same status, pivot
-log, basis and tableau BITS as the oracle's one-pivot-at-a-time loop, for every K, every stop
-reason and every way a pivot limit can cut a block."""
+"""GPU parity tests of the K-pivots-per-sweep paths (opts.block): deciding K pivots ahead from
+O(R + C) data and applying them in one sweep must give the same status, pivot log, basis and
+tableau BITS as the oracle's one-pivot-at-a-time loop, for every K, every stop reason and every
+way a pivot limit can cut a block.  Two implementations: csrc/overlap_kernels.hip (default on
+large tableaux: out-of-place sweep with the next block's loop heads inside the same launch,
+variant 0x50tr; and the default, variant 0x40tr: all loop heads of a block in one persistent
+launch, then the sweep in place) and csrc/block_kernels.hip (in place, one launch per loop head,
+variant 0x60tr)."""
 import hashlib
 
 import numpy as np
@@ -11,7 +15,12 @@ import lp_cases
 
 pytestmark = pytest.mark.gpu
 
-BLOCKS = [2, 3, 4, 8]
+SEQ, OV, INPLACE = 0x4008, 0x5008, 0x6008
+NAMES = {SEQ: "seq", OV: "ov", INPLACE: "inplace"}
+# (variant, block)
+BLOCKS = [(SEQ, 2), (SEQ, 5), (SEQ, 8), (SEQ, 16), (OV, 2), (OV, 3), (OV, 8), (OV, 16),
+          (INPLACE, 2), (INPLACE, 4), (INPLACE, 8)]
+IDS = [NAMES[v] + str(b) for v, b in BLOCKS]
 
 
 def _build(oracle, case):
@@ -20,8 +29,8 @@ def _build(oracle, case):
     return oracle.primal_build(o, A, rel, rhs, is_max, ncoef)
 
 
-@pytest.mark.parametrize("block", BLOCKS)
-def test_named_cases_match_oracle(engine, oracle, block):
+@pytest.mark.parametrize("variant,block", BLOCKS, ids=IDS)
+def test_named_cases_match_oracle(engine, oracle, variant, block):
     from lpr_381_group_v22_amd import Tableau
     statuses = set()
     for name, case in lp_cases.all_cases():
@@ -30,7 +39,7 @@ def test_named_cases_match_oracle(engine, oracle, block):
             continue
         tab = Tableau.from_array(engine, T, basis)
         st, piv, log = oracle.primal_solve(T, basis, 5000)
-        res = tab.solve(max_pivots=5000, block=block)
+        res = tab.solve(max_pivots=5000, block=block, variant=variant)
         assert res.block == block, name
         assert res.status == st and res.pivots == piv, (name, res.status, st, res.pivots, piv)
         assert tab.pivot_log().tolist() == log.tolist(), name
@@ -41,25 +50,25 @@ def test_named_cases_match_oracle(engine, oracle, block):
     assert {0, 1} <= statuses
 
 
-@pytest.mark.parametrize("block", BLOCKS)
-def test_every_pivot_limit_cuts_the_block_correctly(engine, oracle, block):
+@pytest.mark.parametrize("variant,block", BLOCKS, ids=IDS)
+def test_every_pivot_limit_cuts_the_block_correctly(engine, oracle, variant, block):
     """max_pivots = 0..17 on the same LP: the limit lands on every position inside a block."""
     from lpr_381_group_v22_amd import Tableau
     m, n, seed = 40, 64, 3
     T0, b0 = oracle.gen_dense_tableau(m, n, seed)
-    for limit in range(1, 18):
+    for limit in list(range(1, 20)) + [31, 32, 33, 35]:
         T, basis = T0.copy(), b0.copy()
         st, piv, log = oracle.primal_solve(T, basis, limit)
         tab = Tableau.synthetic(engine, m, n, seed)
-        res = tab.solve(max_pivots=limit, block=block, batch=5)
+        res = tab.solve(max_pivots=limit, block=block, batch=5, variant=variant)
         assert res.status == st and res.pivots == piv, (limit, res.status, st, res.pivots, piv)
         assert tab.pivot_log().tolist() == log.tolist(), limit
         assert tab.read().tobytes() == T.tobytes(), limit
         tab.destroy()
 
 
-@pytest.mark.parametrize("block", BLOCKS)
-def test_resume_after_pivot_limit(engine, oracle, block):
+@pytest.mark.parametrize("variant,block", BLOCKS, ids=IDS)
+def test_resume_after_pivot_limit(engine, oracle, variant, block):
     from lpr_381_group_v22_amd import Tableau
     m, n, seed = 48, 96, 2
     T, basis = oracle.gen_dense_tableau(m, n, seed)
@@ -67,7 +76,7 @@ def test_resume_after_pivot_limit(engine, oracle, block):
     tab = Tableau.synthetic(engine, m, n, seed)
     total = 0
     while True:
-        res = tab.solve(max_pivots=7, batch=3, block=block)
+        res = tab.solve(max_pivots=7, batch=3, block=block, variant=variant)
         total += res.pivots
         assert res.total_pivots == total
         if res.status != 5:
@@ -80,15 +89,17 @@ def test_resume_after_pivot_limit(engine, oracle, block):
     tab.destroy()
 
 
-@pytest.mark.parametrize("block,timed", [(2, False), (4, True), (8, False), (5, True)])
-def test_medium_dense_lp_full_solve(engine, oracle, block, timed):
+@pytest.mark.parametrize("variant,block,timed", [(SEQ, 3, False), (SEQ, 16, True), (OV, 2, False), (OV, 4, True), (OV, 16, False),
+                                                 (OV, 11, True), (INPLACE, 8, False),
+                                                 (INPLACE, 5, True)])
+def test_medium_dense_lp_full_solve(engine, oracle, variant, block, timed):
     """m=200, n=333 to optimality (hundreds of pivots), graph replay and eager+events."""
     from lpr_381_group_v22_amd import Tableau
     m, n, seed = 200, 333, 11
     T, basis = oracle.gen_dense_tableau(m, n, seed)
     st, piv, log = oracle.primal_solve(T, basis, 20000)
     tab = Tableau.synthetic(engine, m, n, seed)
-    res = tab.solve(max_pivots=20000, block=block, time_kernels=timed)
+    res = tab.solve(max_pivots=20000, block=block, time_kernels=timed, variant=variant)
     assert res.status == st == 0 and res.pivots == piv
     assert tab.pivot_log(1 << 16).tolist() == log.tolist()
     assert tab.basis().tolist() == basis.tolist()
@@ -99,21 +110,23 @@ def test_medium_dense_lp_full_solve(engine, oracle, block, timed):
     tab.destroy()
 
 
-@pytest.mark.parametrize("tr", [8, 16, 32])
-def test_sweep_tile_shapes_give_identical_bits(engine, oracle, tr):
+@pytest.mark.parametrize("base,tr", [(0x4000, 4), (0x4000, 8), (0x4000, 16), (0x6000, 8), (0x6000, 16), (0x6000, 32), (0x5000, 4),
+                                     (0x5000, 8), (0x5000, 16)])
+def test_sweep_tile_shapes_give_identical_bits(engine, oracle, base, tr):
     from lpr_381_group_v22_amd import Tableau
     m, n, seed = 150, 260, 5
     T, basis = oracle.gen_dense_tableau(m, n, seed)
     st, piv, log = oracle.primal_solve(T, basis, 90)
     tab = Tableau.synthetic(engine, m, n, seed)
-    res = tab.solve(max_pivots=90, block=4, variant=0x6000 | tr)
+    res = tab.solve(max_pivots=90, block=4, variant=base | tr)
     assert res.status == st and res.pivots == piv and res.block == 4
     assert tab.pivot_log().tolist() == log.tolist()
     assert tab.read().tobytes() == T.tobytes()
     tab.destroy()
 
 
-def test_repeated_rows_and_columns_inside_a_block(engine, oracle):
+@pytest.mark.parametrize("variant,block", [(SEQ, 8), (SEQ, 16), (OV, 8), (OV, 16), (INPLACE, 8)])
+def test_repeated_rows_and_columns_inside_a_block(engine, oracle, variant, block):
     """Degenerate / tie-heavy LPs: the same row leaves twice within one block, a column re-enters,
     ties in both arg-mins -- the chains through earlier pivots must reproduce them exactly."""
     from lpr_381_group_v22_amd import Tableau
@@ -130,7 +143,7 @@ def test_repeated_rows_and_columns_inside_a_block(engine, oracle):
         for k in range(0, len(rows), 8):
             seen_repeat |= len(set(rows[k:k + 8])) < len(rows[k:k + 8])
             seen_col_repeat |= len(set(cols[k:k + 8])) < len(cols[k:k + 8])
-        res = tab.solve(max_pivots=400, block=8)
+        res = tab.solve(max_pivots=400, block=block, variant=variant)
         assert res.status == st and res.pivots == piv, seed
         assert tab.pivot_log().tolist() == log.tolist(), seed
         assert tab.read().tobytes() == T.tobytes(), seed
@@ -138,14 +151,15 @@ def test_repeated_rows_and_columns_inside_a_block(engine, oracle):
     assert seen_repeat and seen_col_repeat, "fixtures no longer repeat a pivot row / column inside a block"
 
 
-def test_wide_and_tall_shapes(engine, oracle):
+@pytest.mark.parametrize("variant", [SEQ, OV, INPLACE])
+def test_wide_and_tall_shapes(engine, oracle, variant):
     """ld wider than one head trip (G * 256 double2 < ld / 2) and tall thin tableaux."""
     from lpr_381_group_v22_amd import Tableau
     for (m, n, seed) in [(6, 20000, 1), (3000, 10, 2), (2, 5000, 4), (1, 1, 3)]:
         T, basis = oracle.gen_dense_tableau(m, n, seed)
         st, piv, log = oracle.primal_solve(T, basis, 600)
         tab = Tableau.synthetic(engine, m, n, seed)
-        res = tab.solve(max_pivots=600, block=4)
+        res = tab.solve(max_pivots=600, block=4, variant=variant)
         assert res.status == st and res.pivots == piv, (m, n)
         assert tab.pivot_log().tolist() == log.tolist(), (m, n)
         assert tab.basis().tolist() == basis.tolist(), (m, n)
@@ -161,7 +175,7 @@ def test_north_star_size_blocked_equals_one_pivot_path(engine, oracle):
     T, basis = oracle.gen_dense_tableau(m, n, seed)
     st, piv, log = oracle.primal_solve(T, basis, 8)
     a = Tableau.synthetic(engine, m, n, seed)
-    res = a.solve(max_pivots=8, block=8)
+    res = a.solve(max_pivots=8, block=8, variant=INPLACE)
     assert res.status == st == 5 and res.pivots == 8 and res.block == 8
     assert a.pivot_log().tolist() == log.tolist()
     assert hashlib.sha256(a.read().tobytes()).hexdigest() == \
@@ -169,7 +183,7 @@ def test_north_star_size_blocked_equals_one_pivot_path(engine, oracle):
     del T
     b = Tableau.synthetic(engine, m, n, seed)
     b.solve(max_pivots=8, block=1)
-    ra = a.solve(max_pivots=96)            # auto block
+    ra = a.solve(max_pivots=96)            # auto: fused heads + in-place sweep
     rb = b.solve(max_pivots=96, block=1)
     assert ra.block > 1 and rb.block == 1
     assert ra.pivots == rb.pivots == 96 and ra.z == rb.z
