@@ -116,7 +116,7 @@ typedef struct lpr_solve_opts {
     int32_t batch;         /* pivots queued between host polls of the device status word (0: auto) */
     int32_t variant;       /* rank-1 update kernel variant (0: auto); for tuning only, same bits */
     int32_t block;         /* pivots decided ahead and applied per sweep of the tableau on large
-                              tableaux: 0 auto, 1 one pivot per sweep, 2..8 that many.  The bits
+                              tableaux: 0 auto (16), 1 one pivot per sweep, 2..16 that many.  The bits
                               stored are the same for every value (each element goes through the
                               same sequence of rounded operations, in registers). */
 } lpr_solve_opts;

@@ -26,7 +26,6 @@
 #include "engine_common.hpp"
 #include "select_common.hpp"
 
-#include <cstdlib>
 #include <new>
 
 #pragma clang fp contract(off)
@@ -370,7 +369,7 @@ __global__ __launch_bounds__(kBlkHeadNT) void k_blk_head(
 // its first store, serpentine order over the grid on alternate blocks.  The lanes that own the
 // next entering column / the RHS column dump their final values densely for the next head.
 template <int TR>
-__global__ __launch_bounds__(256) void k_blk_update(double* __restrict__ T, double* Tout, int ld, int R, int C,
+__global__ __launch_bounds__(256) void k_blk_update(double* __restrict__ T, int ld, int R, int C,
                                                     const double* __restrict__ prow,
                                                     const double* __restrict__ fcol, int Rp,
                                                     double* __restrict__ next_col,
@@ -402,7 +401,6 @@ __global__ __launch_bounds__(256) void k_blk_update(double* __restrict__ T, doub
         p[s] = (s < K) ? prow2[(size_t)s * ld2 + c2] : make_double2(0.0, 0.0);
     }
     double2* __restrict__ T2 = reinterpret_cast<double2*>(T);
-    double2* O2 = reinterpret_cast<double2*>(Tout);
     const int rhs = C - 1;
     const bool own_rhs = (c2 == (rhs >> 1));
     const bool own_ne = (ne >= 0 && c2 == (ne >> 1));
@@ -431,7 +429,7 @@ __global__ __launch_bounds__(256) void k_blk_update(double* __restrict__ T, doub
                     }
                 }
             }
-            O2[(size_t)i * ld2 + c2] = t;
+            T2[(size_t)i * ld2 + c2] = t;
             if (own_ne) next_col[i] = (ne & 1) ? t.y : t.x;
             if (own_rhs) next_rhs[i] = (rhs & 1) ? t.y : t.x;
         }
@@ -455,7 +453,6 @@ struct lpr_block_ctx {
 
 namespace lpr {
 
-static double* g_oop = nullptr;  // DIAG
 int blk_max_pivots() { return kBlkMax; }
 
 void blk_release(lpr_tableau* t) {
@@ -501,7 +498,6 @@ int blk_ensure(lpr_tableau* t) {
     LPR_HIP(hipMemsetAsync(c->zrow, 0, (size_t)c->ld * D, s));
     LPR_HIP(hipMemsetAsync(c->bvec, 0, (size_t)2 * c->Rp * D, s));
     std::memset(c->h_state, 0, sizeof(BlockState));
-    if (getenv("LPR_BLK_OOP") && !g_oop) hipMalloc(&g_oop, (size_t)t->rows * t->ld * 8);  // DIAG
     return LPR_OK_OPTIMAL;
 }
 
@@ -575,22 +571,21 @@ void blk_launch_heads(lpr_tableau* t, int K) {
 
 void blk_launch_update(lpr_tableau* t, int tr) {
     lpr_block_ctx* c = static_cast<lpr_block_ctx*>(t->blk);
-    double* Tout = (g_oop && getenv("LPR_BLK_OOP")) ? g_oop : t->T;  // DIAG
     hipStream_t s = t->eng->stream;
     const int G = blk_groups(t);
     const ZPart* zp = reinterpret_cast<const ZPart*>(t->zparts);
     const int ld2 = t->ld / 2;
     if (tr >= 32) {
         dim3 grid((ld2 + 255) / 256, (t->rows + 31) / 32);
-        hipLaunchKernelGGL((k_blk_update<32>), grid, dim3(256), 0, s, t->T, Tout, t->ld, t->rows, t->cols,
+        hipLaunchKernelGGL((k_blk_update<32>), grid, dim3(256), 0, s, t->T, t->ld, t->rows, t->cols,
                            c->prow, c->fcol, c->Rp, t->next_col, t->next_rhs, c->state, zp, G);
     } else if (tr >= 16) {
         dim3 grid((ld2 + 255) / 256, (t->rows + 15) / 16);
-        hipLaunchKernelGGL((k_blk_update<16>), grid, dim3(256), 0, s, t->T, Tout, t->ld, t->rows, t->cols,
+        hipLaunchKernelGGL((k_blk_update<16>), grid, dim3(256), 0, s, t->T, t->ld, t->rows, t->cols,
                            c->prow, c->fcol, c->Rp, t->next_col, t->next_rhs, c->state, zp, G);
     } else {
         dim3 grid((ld2 + 255) / 256, (t->rows + 7) / 8);
-        hipLaunchKernelGGL((k_blk_update<8>), grid, dim3(256), 0, s, t->T, Tout, t->ld, t->rows, t->cols,
+        hipLaunchKernelGGL((k_blk_update<8>), grid, dim3(256), 0, s, t->T, t->ld, t->rows, t->cols,
                            c->prow, c->fcol, c->Rp, t->next_col, t->next_rhs, c->state, zp, G);
     }
 }

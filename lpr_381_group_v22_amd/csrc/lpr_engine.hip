@@ -48,7 +48,7 @@ void blk_launch_update(lpr_tableau* t, int tr);
 // overlap_kernels.hip
 int ov_max_pivots();
 void ov_release(lpr_tableau* t);
-int ov_ensure(lpr_tableau* t);
+int ov_ensure(lpr_tableau* t, bool second_buffer);
 int ov_begin(lpr_tableau* t, int64_t iter, int64_t max_iter);
 int ov_set_log(lpr_tableau* t, int parity);
 void ov_launch_step(lpr_tableau* t, int K, int tr, int lp);
@@ -316,7 +316,7 @@ static int solve_fused(lpr_tableau* t, const lpr_solve_opts& o, lpr_solve_result
 
 // Large tableaux: K pivots per sweep (block_kernels.hip).  opts.block: 0 = auto, 1 = the
 // one-pivot-per-sweep path, 2..8 = that many.  opts.variant 0x7fff also forces the one-pivot path.
-static constexpr int kDefaultBlock = 8;
+static constexpr int kDefaultBlock = 16;
 
 static int block_size(const lpr_tableau* t, const lpr_solve_opts& o) {
     // a specific one-pivot update-kernel variant was asked for (0x60tr = this path, tile rows tr)
@@ -438,7 +438,7 @@ static int solve_overlapped(lpr_tableau* t, const lpr_solve_opts& o, int K, int 
                             lpr_solve_result* res) {
     lpr_engine* e = t->eng;
     hipStream_t s = e->stream;
-    int rc = ov_ensure(t);
+    int rc = ov_ensure(t, overlap);
     if (rc != LPR_OK_OPTIMAL) return rc;
     const bool timed = o.time_kernels != 0;
     int nlaunch = o.batch > 0 ? (o.batch + K - 1) / K : (default_batch(t) + K - 1) / K;

@@ -20,7 +20,6 @@
 #include "engine_common.hpp"
 #include "select_common.hpp"
 
-#include <cstdlib>
 #include <new>
 
 #pragma clang fp contract(off)
@@ -32,7 +31,6 @@ constexpr int kOvNT = 256;      // threads per workgroup (heads and tiles)
 constexpr int kOvGroups = 64;   // head workgroups, upper bound
 constexpr unsigned kOvSpinMax = 1u << 22;
 constexpr int kOvTileRows = 32; // rows per sweep workgroup (TR of them in flight at a time)
-constexpr int kOvU = 17;        // dense-vector elements a lane keeps in flight (17 * 256 >= 4097)
 
 struct OvCtl {
     int32_t status;    // kRunning or the final lpr_status
@@ -48,8 +46,6 @@ struct OvCtl {
     int64_t applied;   // pivots swept into the tableau so far
     int64_t max_iter;  // <= 0: no limit
     int64_t log_cap;
-    int64_t dbg[8];    // DIAG
-    int64_t tdbg[4];   // DIAG
 };
 
 struct OvBuffers {      // everything the step kernel touches, passed by value
@@ -131,8 +127,10 @@ __device__ __forceinline__ bool ov_barrier(unsigned* bar, unsigned target) {
 
 // ------------------------------------------------------------------------------------------
 // The heads of the next block (workgroups [0, G)).
+template <int NT>
 __device__ void ov_heads(const OvBuffers B, int ld, int R, int C, int Rp, int K, int G, int lp,
                          bool solo) {
+    constexpr int kOvU = (4608 + NT - 1) / NT;  // dense-vector elements a lane keeps in flight
     __shared__ double lds_v[16];
     __shared__ int lds_i[16];
     __shared__ double lds_p[2];
@@ -171,14 +169,11 @@ __device__ void ov_heads(const OvBuffers B, int ld, int R, int C, int Rp, int K,
     int count = 0;
     int err = 0;
     unsigned nbar = 0;
-    int64_t dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // DIAG
-    const int64_t TS = wall_clock64();  // DIAG
 
     if (status == kRunning && pend_in != kRunning) {
         status_out = pend_in;  // the block staged before is being swept by this very launch
     } else if (status == kRunning) {
         for (int q = 1; q <= K; ++q) {
-            const int64_t T0 = wall_clock64();  // DIAG
             const int64_t pidx = staged0 + q - 1;
             const ZPart* bank_in = B.zparts + (pidx & 1) * kOvGroups;
             ZPart* bank_out = B.zparts + ((pidx + 1) & 1) * kOvGroups;
@@ -192,7 +187,6 @@ __device__ void ov_heads(const OvBuffers B, int ld, int R, int C, int Rp, int K,
                 pend_out = LPR_OK_OPTIMAL;
                 break;
             }
-            const int64_t T1 = wall_clock64();  // DIAG
             // ---- column e of the tableau after all earlier pivots, this workgroup's rows ----
             if (tid < kb) s_pa[tid] = prowA[(size_t)tid * ld + e];
             if (tid >= 32 && tid - 32 < q - 1) s_pn[tid - 32] = prowN[(size_t)(tid - 32) * ld + e];
@@ -237,12 +231,10 @@ __device__ void ov_heads(const OvBuffers B, int ld, int R, int C, int Rp, int K,
                 }
                 colq[i] = c;
             }
-            const int64_t T2 = wall_clock64();  // DIAG
             if (!ov_barrier(bar, (++nbar) * (unsigned)G)) {
                 err = 1;
                 break;
             }
-            const int64_t T3 = wall_clock64();  // DIAG
 
             // ---- FindLeavingVariable (:169-191) on the dense column / RHS ----
             Cand c;
@@ -287,7 +279,6 @@ __device__ void ov_heads(const OvBuffers B, int ld, int R, int C, int Rp, int K,
             if (my_best == r) lds_p[0] = a_of_best;
             if (tid == 0) s_r[q - 1] = r;
             __syncthreads();
-            const int64_t T4 = wall_clock64();  // DIAG
             const double p = lds_p[0];
             const double f0 = lds_p[1];
 
@@ -413,8 +404,6 @@ __device__ void ov_heads(const OvBuffers B, int ld, int R, int C, int Rp, int K,
                 }
             }
             count = q;
-            const int64_t T5 = wall_clock64();  // DIAG
-            dbg[0] += T1 - T0; dbg[1] += T2 - T1; dbg[2] += T3 - T2; dbg[3] += T4 - T3; dbg[4] += T5 - T4;  // DIAG
             if (!ov_barrier(bar, (++nbar) * (unsigned)G)) {
                 err = 1;
                 break;
@@ -432,8 +421,6 @@ __device__ void ov_heads(const OvBuffers B, int ld, int R, int C, int Rp, int K,
         co->max_iter = mx;
         co->log_cap = log_cap;
         co->error = err | ci->error;
-        dbg[5] = wall_clock64() - TS; dbg[6] = count; dbg[7] = TS;  // DIAG
-        for (int k = 0; k < 8; ++k) co->dbg[k] = dbg[k];  // DIAG
         B.bar[lp ^ 1] = 0u;  // nobody touches the other counter during this launch
         if (solo) {  // no sweep in this launch: its fields are carried over here
             co->applied = ci->applied;
@@ -543,7 +530,7 @@ template <int TR>
 __global__ __launch_bounds__(kOvNT) void k_ov_step(const OvBuffers B, int ld, int R, int C, int Rp,
                                                    int K, int G, int lp) {
     if ((int)blockIdx.x < G)
-        ov_heads(B, ld, R, C, Rp, K, G, lp, false);
+        ov_heads<kOvNT>(B, ld, R, C, Rp, K, G, lp, false);
     else
         ov_tiles<TR, false>(B, ld, R, Rp, G, lp);
 }
@@ -551,9 +538,10 @@ __global__ __launch_bounds__(kOvNT) void k_ov_step(const OvBuffers B, int ld, in
 // The same two halves as separate launches: all K loop heads of a block in ONE persistent launch
 // (no sweep running: nothing to chain through but the block's own pivots), then the sweep in
 // place.  Heads always run on control block 0, the sweep on control block 1.
-__global__ __launch_bounds__(kOvNT) void k_ov_heads(const OvBuffers B, int ld, int R, int C, int Rp,
-                                                    int K, int G) {
-    ov_heads(B, ld, R, C, Rp, K, G, 0, true);
+template <int NT>
+__global__ __launch_bounds__(NT) void k_ov_heads(const OvBuffers B, int ld, int R, int C, int Rp,
+                                                 int K, int G) {
+    ov_heads<NT>(B, ld, R, C, Rp, K, G, 0, true);
 }
 
 template <int TR>
@@ -593,9 +581,10 @@ void ov_release(lpr_tableau* t) {
     t->ov = nullptr;
 }
 
-int ov_ensure(lpr_tableau* t) {
+int ov_ensure(lpr_tableau* t, bool second_buffer) {
     lpr_overlap_ctx* c = static_cast<lpr_overlap_ctx*>(t->ov);
-    if (c && c->rows == t->rows && c->ld == t->ld) return LPR_OK_OPTIMAL;
+    if (c && c->rows == t->rows && c->ld == t->ld && (c->T2 || !second_buffer))
+        return LPR_OK_OPTIMAL;
     ov_release(t);
     c = new (std::nothrow) lpr_overlap_ctx();
     if (!c) return LPR_OUT_OF_MEMORY;
@@ -606,7 +595,7 @@ int ov_ensure(lpr_tableau* t) {
     auto chk = [&](hipError_t x) { if (err == hipSuccess) err = x; };
     const size_t D = sizeof(double);
     const size_t tbytes = (size_t)t->rows * t->ld * D;
-    chk(hipMalloc(&c->T2, tbytes));
+    if (second_buffer) chk(hipMalloc(&c->T2, tbytes));
     chk(hipMalloc(&c->b.prow, (size_t)2 * kOvMax * c->ld * D));
     chk(hipMalloc(&c->b.fcol, (size_t)2 * kOvMax * c->Rp * D));
     chk(hipMalloc(&c->b.zrow, (size_t)c->ld * D));
@@ -622,7 +611,7 @@ int ov_ensure(lpr_tableau* t) {
         return err == hipErrorOutOfMemory ? LPR_OUT_OF_MEMORY : LPR_DEVICE_ERROR;
     }
     hipStream_t s = t->eng->stream;
-    LPR_HIP(hipMemsetAsync(c->T2, 0, tbytes, s));
+    if (c->T2) LPR_HIP(hipMemsetAsync(c->T2, 0, tbytes, s));
     LPR_HIP(hipMemsetAsync(c->b.prow, 0, (size_t)2 * kOvMax * c->ld * D, s));
     LPR_HIP(hipMemsetAsync(c->b.fcol, 0, (size_t)2 * kOvMax * c->Rp * D, s));
     LPR_HIP(hipMemsetAsync(c->b.zrow, 0, (size_t)c->ld * D, s));
@@ -695,9 +684,20 @@ void ov_launch_step(lpr_tableau* t, int K, int tr, int lp) {
 
 void ov_launch_heads(lpr_tableau* t, int K) {
     lpr_overlap_ctx* c = static_cast<lpr_overlap_ctx*>(t->ov);
-    const int G = ov_groups(t);
-    hipLaunchKernelGGL(k_ov_heads, dim3(G), dim3(kOvNT), 0, t->eng->stream, c->b, t->ld, t->rows,
-                       t->cols, c->Rp, K, G);
+    const int nt = kOvNT;  // 512 measures the same, 1024 slower
+    int G = (t->ld / 2 + nt - 1) / nt;
+    if (G < 1) G = 1;
+    if (G > kOvGroups) G = kOvGroups;
+    hipStream_t s = t->eng->stream;
+    if (nt >= 1024)
+        hipLaunchKernelGGL((k_ov_heads<1024>), dim3(G), dim3(1024), 0, s, c->b, t->ld, t->rows,
+                           t->cols, c->Rp, K, G);
+    else if (nt >= 512)
+        hipLaunchKernelGGL((k_ov_heads<512>), dim3(G), dim3(512), 0, s, c->b, t->ld, t->rows,
+                           t->cols, c->Rp, K, G);
+    else
+        hipLaunchKernelGGL((k_ov_heads<256>), dim3(G), dim3(256), 0, s, c->b, t->ld, t->rows,
+                           t->cols, c->Rp, K, G);
 }
 
 void ov_launch_sweep(lpr_tableau* t, int tr) {
@@ -727,14 +727,6 @@ int ov_poll(lpr_tableau* t, int parity, int32_t* status, int32_t* cur, int64_t* 
     *cur = c->h_ctl[parity].cur;
     *applied = c->h_ctl[parity].applied;
     *error = c->h_ctl[parity].error;
-    if (getenv("LPR_OV_DIAG")) {  // DIAG
-        const int64_t* d = c->h_ctl[parity].dbg;
-        fprintf(stderr, "[ov diag x10ns] zparts %lld gather %lld bar1 %lld ratio %lld row %lld | heads total %lld pivots %lld\n",
-                (long long)d[0], (long long)d[1], (long long)d[2], (long long)d[3], (long long)d[4], (long long)d[5], (long long)d[6]);
-        const int64_t* td = c->h_ctl[parity].tdbg;
-        fprintf(stderr, "[ov diag2 x10ns rel. to heads start] first tile %lld..%lld last tile %lld..%lld\n",
-                (long long)(td[0] - d[7]), (long long)(td[1] - d[7]), (long long)(td[2] - d[7]), (long long)(td[3] - d[7]));
-    }
     return LPR_OK_OPTIMAL;
 }
 

@@ -94,3 +94,13 @@ def test_no_fma_in_pivot_kernels():
         assert "v_fma_f64" not in body and "v_fmac_f64" not in body, name
         assert "v_mul_f64" in body and "v_add_f64" in body, name
         assert "global_load_dwordx4" in body and "global_store_dwordx4" in body, name
+    # the K-pivots-per-sweep kernels: the sweeps contain no division at all, so no FMA of any kind
+    for fname, pat in (("block_kernels.s", r"_ZN3lpr12k_blk_update\w+"),
+                       ("overlap_kernels.s", r"_ZN3lpr10k_ov_sweep\w+")):
+        s = open(os.path.join(csrc, "_obj", fname)).read()
+        bodies = re.findall(r"^(" + pat + r"):[^\n]*\n(.*?)\.Lfunc_end", s, flags=re.S | re.M)
+        assert len(bodies) >= 3, fname
+        for name, body in bodies:
+            assert "v_fma_f64" not in body and "v_fmac_f64" not in body, name
+            assert "v_mul_f64" in body and "v_add_f64" in body, name
+            assert "global_load_dwordx4" in body and "global_store_dwordx4" in body, name
