@@ -89,6 +89,25 @@ __global__ __launch_bounds__(1024) void k_ov_prologue(const double* __restrict__
     for (int i = tid; i < R; i += nt) bvec0[i] = T[(size_t)i * ld + (C - 1)];
 }
 
+// Data that the head workgroups hand to each other INSIDE a launch (the gathered column, the
+// normalised row, the RHS column, the partial arg-mins) is written and read with agent-scope
+// relaxed atomics: on gfx950 these are sc1 accesses that are coherent at the memory side across
+// the XCDs' L2s, so the barrier between the phases needs no L2 write-back / invalidate (which
+// costs microseconds per barrier, and under a concurrently running sweep far more).  What a
+// lane wrote itself, and everything written by an earlier launch, is read with plain loads.
+__device__ __forceinline__ double xld(const double* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void xst(double* p, double v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int xld(const int* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void xst(int* p, int v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // arg-min over the G partials, one per lane (G <= 64), every wave on its own
 __device__ __forceinline__ Cand ov_reduce_zparts(const ZPart* bank, int G) {
     const int lane = threadIdx.x & (kWave - 1);
@@ -96,23 +115,25 @@ __device__ __forceinline__ Cand ov_reduce_zparts(const ZPart* bank, int G) {
     c.v = 0.0;
     c.i = -1;
     if (lane < G) {
-        c.v = bank[lane].v;
-        c.i = bank[lane].i;
+        c.v = xld(&bank[lane].v);
+        c.i = xld(&bank[lane].i);
     }
     return wave_cand_min(c);
 }
 
-// Barrier over the G head workgroups.  Returns false when it timed out.
+// Barrier over the G head workgroups.  Returns false when it timed out.  No cache maintenance:
+// the workgroup barrier waits for every lane's (sc1) stores to complete, the arrival and the poll
+// are memory-side atomics, and what is read afterwards is read with sc1 loads (see xld).
 __device__ __forceinline__ bool ov_barrier(unsigned* bar, unsigned target) {
     __shared__ int ok;
+    __builtin_amdgcn_s_waitcnt(0);  // this lane's stores have been acknowledged
     __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence();  // release: this workgroup's writes are visible before it arrives
-        atomicAdd(bar, 1u);
+        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned spins = 0;
         int good = 1;
         while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_s_sleep(1);
             if (++spins > kOvSpinMax) {
                 good = 0;
                 break;
@@ -121,7 +142,6 @@ __device__ __forceinline__ bool ov_barrier(unsigned* bar, unsigned target) {
         ok = good;
     }
     __syncthreads();
-    __threadfence();  // acquire: drop this CU's stale lines before reading the others' results
     return ok != 0;
 }
 
@@ -189,7 +209,7 @@ __device__ void ov_heads(const OvBuffers B, int ld, int R, int C, int Rp, int K,
             }
             // ---- column e of the tableau after all earlier pivots, this workgroup's rows ----
             if (tid < kb) s_pa[tid] = prowA[(size_t)tid * ld + e];
-            if (tid >= 32 && tid - 32 < q - 1) s_pn[tid - 32] = prowN[(size_t)(tid - 32) * ld + e];
+            if (tid >= 32 && tid - 32 < q - 1) s_pn[tid - 32] = xld(&prowN[(size_t)(tid - 32) * ld + e]);
             __syncthreads();
             for (int i = g * nt + tid; i < R; i += G * nt) {
                 double c = Tin[(size_t)i * ld + e];
@@ -229,7 +249,7 @@ __device__ void ov_heads(const OvBuffers B, int ld, int R, int C, int Rp, int K,
                         }
                     }
                 }
-                colq[i] = c;
+                xst(&colq[i], c);
             }
             if (!ov_barrier(bar, (++nbar) * (unsigned)G)) {
                 err = 1;
@@ -246,8 +266,8 @@ __device__ void ov_heads(const OvBuffers B, int ld, int R, int C, int Rp, int K,
 #pragma unroll
                 for (int u = 0; u < kOvU; ++u) {
                     const int i = i0 + u * nt;
-                    a[u] = (i < R) ? colq[i] : 0.0;
-                    b[u] = (i < R) ? bprev[i] : 0.0;
+                    a[u] = (i < R) ? xld(&colq[i]) : 0.0;
+                    b[u] = (i < R) ? xld(&bprev[i]) : 0.0;
                 }
 #pragma unroll
                 for (int u = 0; u < kOvU; ++u) {
@@ -285,9 +305,9 @@ __device__ void ov_heads(const OvBuffers B, int ld, int R, int C, int Rp, int K,
             // ---- row r after all earlier pivots, normalised (:199); next Z row; partial ----
             // f_t[r] of every earlier pivot, once per workgroup
             if (tid < kb) s_fa[tid] = fcolA[(size_t)tid * Rp + r];
-            if (tid >= 32 && tid - 32 < q - 1) s_fn[tid - 32] = fcolN[(size_t)(tid - 32) * Rp + r];
+            if (tid >= 32 && tid - 32 < q - 1) s_fn[tid - 32] = xld(&fcolN[(size_t)(tid - 32) * Rp + r]);
             if (tid >= 64 && tid - 64 < kb) s_pa[tid - 64] = prowA[(size_t)(tid - 64) * ld + rhs];
-            if (tid >= 96 && tid - 96 < q - 1) s_pn[tid - 96] = prowN[(size_t)(tid - 96) * ld + rhs];
+            if (tid >= 96 && tid - 96 < q - 1) s_pn[tid - 96] = xld(&prowN[(size_t)(tid - 96) * ld + rhs]);
             double wr = (tid == 128) ? Tin[(size_t)r * ld + rhs] : 0.0;
             __syncthreads();
             const double2* Tin2 = reinterpret_cast<const double2*>(Tin);
@@ -348,7 +368,8 @@ __device__ void ov_heads(const OvBuffers B, int ld, int R, int C, int Rp, int K,
                 double2 pq;
                 pq.x = (j < C) ? w.x / p : 0.0;  // :199 true division
                 pq.y = (j + 1 < C) ? w.y / p : 0.0;
-                prowN2[(size_t)(q - 1) * ld2 + c2] = pq;
+                xst(&prowN[(size_t)(q - 1) * ld + 2 * c2], pq.x);
+                xst(&prowN[(size_t)(q - 1) * ld + 2 * c2 + 1], pq.y);
                 const double mxp = f0 * pq.x;  // :208 product rounded, then the difference
                 const double myp = f0 * pq.y;
                 z.x = z.x - mxp;
@@ -388,12 +409,12 @@ __device__ void ov_heads(const OvBuffers B, int ld, int R, int C, int Rp, int K,
             __syncthreads();
             const double prhs = lds_p[0];
             for (int i = g * nt + tid; i < R; i += G * nt) {
-                const double prod = colq[i] * prhs;
-                bnew[i] = (i == r) ? prhs : bprev[i] - prod;
+                const double prod = colq[i] * prhs;  // own rows: written by this lane above
+                xst(&bnew[i], (i == r) ? prhs : bprev[i] - prod);
             }
             if (tid == 0) {
-                bank_out[g].v = n.v;
-                bank_out[g].i = n.i;
+                xst(&bank_out[g].v, n.v);
+                xst(&bank_out[g].i, n.i);
                 if (lead) {
                     co->r[q - 1] = r;
                     B.basis[r - 1] = e;  // :142
