@@ -159,9 +159,15 @@ def run_primal(args, D: Dist):
             # launch applies.  With block > 1 the sweep still moves each element once, so the
             # algorithmic rate can exceed the HBM peak; `traffic` is what physically moved.
             achieved = block * bytes_per_pivot / (kern_ms * 1e-3) / 1e9
-            kname = "k_update (rank-1 row elimination)" if block == 1 else \
-                f"k_ov_sweep ({block} pivots per sweep: each element read once, taken through " \
-                f"{block} rounded multiply-subtract steps in registers, written once)"
+            if block == 1:
+                kname = "k_update (rank-1 row elimination)"
+            elif (args.variant & 0xff00) in (0x4000, 0x6000):
+                kname = (f"sweep of {block} pivots (each element read once, taken through "
+                         f"{block} rounded multiply-subtract steps in registers, written once)")
+            else:
+                kname = (f"k_ov_step: sweep of {block} pivots (each element read once, taken "
+                         f"through {block} rounded multiply-subtract steps in registers, written "
+                         f"once) with the loop heads of the next {block} pivots in the same launch")
             roof = {"bound": "hbm", "kernel": kname,
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 4),
@@ -179,9 +185,8 @@ def run_primal(args, D: Dist):
                     "achieved/frac follow the contract (algorithmic bytes of the pivots one launch "
                     "applies / launch time) and exceed the HBM peak because the sweep moves each "
                     "element once for all its pivots; hbm_side_frac is the physical traffic "
-                    "(PMC) / launch time / peak.  The loop heads that decide the pivots "
-                    "(k_ov_heads, latency-bound, O(R+C) data per pivot) take the rest of "
-                    "ms_per_step.")
+                    "(PMC) / launch time / peak.  The launch lasts as long as its loop heads "
+                    "(latency-bound, O(R+C) data per pivot), not as long as its sweep.")
         cpu = None
         if D.world == 1 and args.cpu_pivots != 0:
             cp = args.cpu_pivots

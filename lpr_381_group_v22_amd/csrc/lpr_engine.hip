@@ -796,11 +796,13 @@ int lpr_primal_solve(lpr_tableau* t, const lpr_solve_opts* opts, lpr_solve_resul
         // variant 0x60tr: in-place blocked path; 0x50tr or none: the overlapped path
         const int K = block_size(t, o);
         if (K > 1 && (o.variant & 0xff00) == 0x6000) return solve_blocked(t, o, K, res);
-        // 0x50tr: sweep out of place with the next block's heads inside the same launch;
-        // default / 0x40tr: all heads of a block in one persistent launch, then the sweep in place
+        // default / 0x50tr: sweep out of place with the next block's heads inside the same launch;
+        // 0x40tr: all heads of a block in one persistent launch, then the sweep in place (also the
+        // fallback when the second tableau buffer cannot be allocated)
         if (K > 1) {
-            const bool overlap = (o.variant & 0xff00) == 0x5000;
+            bool overlap = (o.variant & 0xff00) != 0x4000;
             const int tr = (o.variant & 0xff00) ? (o.variant & 0xff) : 8;
+            if (overlap && ov_ensure(t, true) == LPR_OUT_OF_MEMORY) overlap = false;
             return solve_overlapped(t, o, K, tr, overlap, res);
         }
     }

@@ -213,13 +213,13 @@ __device__ void ov_heads(const OvBuffers B, int ld, int R, int C, int Rp, int K,
             __syncthreads();
             for (int i = g * nt + tid; i < R; i += G * nt) {
                 double c = Tin[(size_t)i * ld + e];
-                for (int t0 = 0; t0 < kb; t0 += 8) {  // through the block being swept
-                    double f[8];
+                for (int t0 = 0; t0 < kb; t0 += kOvMax) {  // through the block being swept
+                    double f[kOvMax];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u)
+                    for (int u = 0; u < kOvMax; ++u)
                         f[u] = (t0 + u < kb) ? fcolA[(size_t)(t0 + u) * Rp + i] : 0.0;
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
+                    for (int u = 0; u < kOvMax; ++u) {
                         const int t = t0 + u;
                         if (t < kb) {
                             if (i == rA[t]) {
@@ -320,14 +320,14 @@ __device__ void ov_heads(const OvBuffers B, int ld, int R, int C, int Rp, int K,
             for (int c2 = g * nt + tid; c2 < ld2; c2 += G * nt) {
                 double2 w = Tin2[(size_t)r * ld2 + c2];
                 double2 z = zrow2[c2];
-                for (int t0 = 0; t0 < kb; t0 += 8) {
-                    double2 ps[8];
+                for (int t0 = 0; t0 < kb; t0 += kOvMax) {
+                    double2 ps[kOvMax];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u)
+                    for (int u = 0; u < kOvMax; ++u)
                         ps[u] = (t0 + u < kb) ? prowA2[(size_t)(t0 + u) * ld2 + c2]
                                               : make_double2(0.0, 0.0);
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
+                    for (int u = 0; u < kOvMax; ++u) {
                         const int t = t0 + u;
                         if (t < kb) {
                             if (r == rA[t]) {
