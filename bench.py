@@ -176,6 +176,11 @@ def run_primal(args, D: Dist):
                     "avg_launch_ms": round(kern_ms, 6), "launches": launches,
                     "event_sampling": "every 4th sweep launch of the timed region",
                     "traffic": None}
+            # SURVEY 8(d)'s whole-job form of the same figure: bytes/pivot x pivots/s
+            whole = bytes_per_pivot * value / D.world / 1e9
+            roof["achieved_whole_job"] = round(whole, 1)
+            roof["frac_whole_job"] = round(whole / HBM_PEAK_GBPS, 4)
+            roof["frac_vs_measured_copy_6290"] = round(achieved / 6290.0, 4)
             roof.update(_pmc_traffic(m, n, block))
             if roof.get("traffic"):
                 roof["hbm_side_frac"] = round(roof["traffic"] / (kern_ms * 1e-3) / 1e9
