@@ -200,7 +200,7 @@ static int default_batch(const lpr_tableau* t) {
 
 // Small tableaux (<= kFusedBytes): one k_pivot_fused launch per pivot, ping-pong between T and
 // T2.  opts.variant == 0x7fff forces the two-kernel path (tests), 0x7ffe forces the fused one.
-static constexpr size_t kFusedBytes = (size_t)16 << 20;
+static constexpr size_t kFusedBytes = (size_t)12 << 20;  // measured cross-over with the K-pivot path
 
 static bool use_fused(const lpr_tableau* t, const lpr_solve_opts& o) {
     if (o.time_kernels) return false;
@@ -245,8 +245,12 @@ static int solve_fused(lpr_tableau* t, const lpr_solve_opts& o, lpr_solve_result
             LPR_HIP(hipMemcpyAsync(&t->state->log_cap, &hs->log_cap, sizeof(int64_t),
                                    hipMemcpyHostToDevice, s));
         }
-        const bool full = (nb == batch);
-        if (full) {  // replay a captured batch (valid for the current T / T2 orientation)
+        // replay a captured batch (valid for the current T / T2 orientation) -- when one exists
+        // already, or when enough work is ahead to pay for capturing it (a few ms)
+        const bool have = t->graph && t->graph_batch == nb && t->graph_variant == -2 &&
+                          t->graph_T == t->T;
+        const bool full = (nb == batch) && (have || max_iter == 0 || max_iter - iter >= 4 * batch);
+        if (full) {
             if (!t->graph || t->graph_batch != nb || t->graph_variant != -2 ||
                 t->graph_T != t->T) {
                 drop_graph(t);
@@ -317,6 +321,7 @@ static int solve_fused(lpr_tableau* t, const lpr_solve_opts& o, lpr_solve_result
 // Large tableaux: K pivots per sweep (block_kernels.hip).  opts.block: 0 = auto, 1 = the
 // one-pivot-per-sweep path, 2..8 = that many.  opts.variant 0x7fff also forces the one-pivot path.
 static constexpr int kDefaultBlock = 16;
+static constexpr size_t kOverlapBytes = (size_t)300 << 20;
 
 static int block_size(const lpr_tableau* t, const lpr_solve_opts& o) {
     // a specific one-pivot update-kernel variant was asked for (0x60tr = this path, tile rows tr)
@@ -800,7 +805,11 @@ int lpr_primal_solve(lpr_tableau* t, const lpr_solve_opts* opts, lpr_solve_resul
         // 0x40tr: all heads of a block in one persistent launch, then the sweep in place (also the
         // fallback when the second tableau buffer cannot be allocated)
         if (K > 1) {
-            bool overlap = (o.variant & 0xff00) != 0x4000;
+            // measured (tools/size_sweep.sh): up to ~230 MB the heads-then-sweep form is faster
+            // (14-22 us per pivot), above it hiding the sweep behind the next heads wins
+            const size_t tbytes = (size_t)t->rows * t->ld * sizeof(double);
+            bool overlap = (o.variant & 0xff00) == 0x5000 ||
+                           ((o.variant & 0xff00) == 0 && tbytes > kOverlapBytes);
             const int tr = (o.variant & 0xff00) ? (o.variant & 0xff) : 8;
             if (overlap && ov_ensure(t, true) == LPR_OUT_OF_MEMORY) overlap = false;
             return solve_overlapped(t, o, K, tr, overlap, res);
