@@ -221,7 +221,8 @@ def run_primal(args, D: Dist):
                        "m": m, "n": n, "rows": R, "cols": C, "seed": "rank",
                        "parallelism": f"replica{D.world}", "update_variant": args.variant,
                        "pivots_per_sweep": block,
-                       "launch": "eager+events" if timed else "hipGraph"},
+                       "launch": ("eager+events" if timed else
+                                  ("hipGraph" if block == 1 else "eager"))},
             "roofline": roof, "cpu_baseline": cpu,
         }
     tab.destroy()

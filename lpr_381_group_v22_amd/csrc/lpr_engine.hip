@@ -472,46 +472,22 @@ static int solve_overlapped(lpr_tableau* t, const lpr_solve_opts& o, int K, int 
             rc = ov_set_log(t, 0);
             if (rc != LPR_OK_OPTIMAL) return rc;
         }
+        // One or two launches per K pivots: plain launches keep the device busy (measured: a
+        // captured graph is no faster here, and capturing one costs milliseconds per solve call).
         if (timed) {
             while ((int)t->ev.size() < 2 * nb) {
                 hipEvent_t ev;
                 LPR_HIP(hipEventCreate(&ev));
                 t->ev.push_back(ev);
             }
-            for (int k = 0; k < nb; ++k) {
-                const bool sample = (k % kTimeStride) == 0;
-                if (!overlap) ov_launch_heads(t, K);
-                if (sample) LPR_HIP(hipEventRecord(t->ev[2 * k], s));
-                if (overlap) ov_launch_step(t, K, tr, k & 1);
-                else ov_launch_sweep(t, tr);
-                if (sample) LPR_HIP(hipEventRecord(t->ev[2 * k + 1], s));
-            }
-        } else {
-            const int gv = (overlap ? -1000 : -3000) - K * 64 - tr;  // graph key of this path
-            if (!t->graph || t->graph_batch != nb || t->graph_variant != gv) {
-                drop_graph(t);
-                hipGraph_t g = nullptr;
-                LPR_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-                for (int k = 0; k < nb; ++k) {
-                    if (overlap) {
-                        ov_launch_step(t, K, tr, k & 1);
-                    } else {
-                        ov_launch_heads(t, K);
-                        ov_launch_sweep(t, tr);
-                    }
-                }
-                LPR_HIP(hipStreamEndCapture(s, &g));
-                hipError_t ierr = hipGraphInstantiate(&t->graph, g, nullptr, nullptr, 0);
-                hipGraphDestroy(g);
-                if (ierr != hipSuccess) {
-                    t->graph = nullptr;
-                    set_error("hipGraphInstantiate failed: %s", hipGetErrorString(ierr));
-                    return LPR_DEVICE_ERROR;
-                }
-                t->graph_batch = nb;
-                t->graph_variant = gv;
-            }
-            LPR_HIP(hipGraphLaunch(t->graph, s));
+        }
+        for (int k = 0; k < nb; ++k) {
+            const bool sample = timed && (k % kTimeStride) == 0;
+            if (!overlap) ov_launch_heads(t, K);
+            if (sample) LPR_HIP(hipEventRecord(t->ev[2 * k], s));
+            if (overlap) ov_launch_step(t, K, tr, k & 1);
+            else ov_launch_sweep(t, tr);
+            if (sample) LPR_HIP(hipEventRecord(t->ev[2 * k + 1], s));
         }
         LPR_HIP(hipGetLastError());
         int64_t now = applied;
@@ -542,7 +518,6 @@ static int solve_overlapped(lpr_tableau* t, const lpr_solve_opts& o, int K, int 
             return LPR_DEVICE_ERROR;
         }
     }
-    drop_graph(t);  // the captured launches hold the buffer pointers of this call
     ov_adopt_buffer(t, cur);
     t->total_pivots = applied;
     res->status = status;
