@@ -55,6 +55,7 @@ struct OvBuffers {      // everything the step kernel touches, passed by value
     double* zrow;       // [ld]  Z row of the tableau after all staged pivots
     double* bvec;       // [2][Rp] RHS column after `staged` pivots in bvec[staged & 1]
     ZPart* zparts;      // [2][kOvGroups]
+    double* rparts;     // [3][kOvGroups] ratio-test partials: ratio, pivot element, row (as double); + f0
     OvCtl* ctl;         // [2]
     unsigned* bar;      // [2]
     int32_t* basis;
@@ -150,7 +151,6 @@ __device__ __forceinline__ bool ov_barrier(unsigned* bar, unsigned target) {
 template <int NT>
 __device__ void ov_heads(const OvBuffers B, int ld, int R, int C, int Rp, int K, int G, int lp,
                          bool solo) {
-    constexpr int kOvU = (4608 + NT - 1) / NT;  // dense-vector elements a lane keeps in flight
     __shared__ double lds_v[16];
     __shared__ int lds_i[16];
     __shared__ double lds_p[2];
@@ -211,6 +211,10 @@ __device__ void ov_heads(const OvBuffers B, int ld, int R, int C, int Rp, int K,
             if (tid < kb) s_pa[tid] = prowA[(size_t)tid * ld + e];
             if (tid >= 32 && tid - 32 < q - 1) s_pn[tid - 32] = xld(&prowN[(size_t)(tid - 32) * ld + e]);
             __syncthreads();
+            Cand rc;
+            rc.v = DBL_MAX;
+            rc.i = -1;
+            double a_of_best = 0.0;
             for (int i = g * nt + tid; i < R; i += G * nt) {
                 double c = Tin[(size_t)i * ld + e];
                 for (int t0 = 0; t0 < kb; t0 += kOvMax) {  // through the block being swept
@@ -250,44 +254,61 @@ __device__ void ov_heads(const OvBuffers B, int ld, int R, int C, int Rp, int K,
                     }
                 }
                 xst(&colq[i], c);
+                // FindLeavingVariable (:169-191) on this lane's rows: its RHS entries are its own
+                if (i == 0) xst(&B.rparts[3 * kOvGroups], c);  // T[0, e], the Z row's factor
+                if (i >= 1 && c > 1e-9) {
+                    const double ratio = bprev[i] / c;
+                    if (ratio >= 0 && ratio < rc.v) {
+                        rc.v = ratio;
+                        rc.i = i;
+                        a_of_best = c;
+                    }
+                }
+            }
+            {   // this workgroup's (ratio, row) minimum and its pivot element -> the partials
+                const int my_best = rc.i;
+                rc = block_cand_min(rc, lds_v, lds_i);
+                if (rc.i >= 0 && my_best == rc.i) lds_p[0] = a_of_best;  // one lane owns that row
+                __syncthreads();
+                if (tid == 0) {
+                    xst(&B.rparts[g], rc.v);
+                    xst(&B.rparts[kOvGroups + g], rc.i >= 0 ? lds_p[0] : 0.0);
+                    xst(&B.rparts[2 * kOvGroups + g], (double)rc.i);
+                }
             }
             if (!ov_barrier(bar, (++nbar) * (unsigned)G)) {
                 err = 1;
                 break;
             }
 
-            // ---- FindLeavingVariable (:169-191) on the dense column / RHS ----
-            Cand c;
-            c.v = DBL_MAX;
-            c.i = -1;
-            double a_of_best = 0.0;
-            for (int i0 = tid; i0 < R; i0 += kOvU * nt) {
-                double a[kOvU], b[kOvU];
-#pragma unroll
-                for (int u = 0; u < kOvU; ++u) {
-                    const int i = i0 + u * nt;
-                    a[u] = (i < R) ? xld(&colq[i]) : 0.0;
-                    b[u] = (i < R) ? xld(&bprev[i]) : 0.0;
+            // ---- the leaving row: lexicographic minimum of the G partials (every wave on its own)
+            double p, f0;
+            int r;
+            {
+                const int lane = tid & (kWave - 1);
+                Cand c;
+                c.v = DBL_MAX;
+                c.i = -1;
+                double a = 0.0;
+                if (lane < G) {
+                    c.v = xld(&B.rparts[lane]);
+                    a = xld(&B.rparts[kOvGroups + lane]);
+                    c.i = (int)xld(&B.rparts[2 * kOvGroups + lane]);
                 }
+                f0 = xld(&B.rparts[3 * kOvGroups]);
 #pragma unroll
-                for (int u = 0; u < kOvU; ++u) {
-                    const int i = i0 + u * nt;
-                    if (i < R) {
-                        if (i == 0) lds_p[1] = a[u];
-                        if (i >= 1 && a[u] > 1e-9) {
-                            const double ratio = b[u] / a[u];
-                            if (ratio >= 0 && ratio < c.v) {
-                                c.v = ratio;
-                                c.i = i;
-                                a_of_best = a[u];
-                            }
-                        }
-                    }
+                for (int off = 32; off > 0; off >>= 1) {
+                    Cand o;
+                    o.v = __shfl_xor(c.v, off, kWave);
+                    o.i = __shfl_xor(c.i, off, kWave);
+                    const double oa = __shfl_xor(a, off, kWave);
+                    const Cand m = cand_min(c, o);
+                    if (m.i != c.i || m.v != c.v) a = oa;  // the other side won
+                    c = m;
                 }
+                r = c.i;
+                p = a;
             }
-            const int my_best = c.i;
-            c = block_cand_min(c, lds_v, lds_i);
-            const int r = c.i;
             if (r < 0) {
                 pend_out = LPR_UNBOUNDED;
                 break;
@@ -296,11 +317,7 @@ __device__ void ov_heads(const OvBuffers B, int ld, int R, int C, int Rp, int K,
                 pend_out = LPR_PIVOT_LIMIT;
                 break;
             }
-            if (my_best == r) lds_p[0] = a_of_best;
             if (tid == 0) s_r[q - 1] = r;
-            __syncthreads();
-            const double p = lds_p[0];
-            const double f0 = lds_p[1];
 
             // ---- row r after all earlier pivots, normalised (:199); next Z row; partial ----
             // f_t[r] of every earlier pivot, once per workgroup
@@ -595,6 +612,7 @@ void ov_release(lpr_tableau* t) {
     hipFree(c->b.zrow);
     hipFree(c->b.bvec);
     hipFree(c->b.zparts);
+    hipFree(c->b.rparts);
     hipFree(c->b.ctl);
     hipFree(c->b.bar);
     if (c->h_ctl) hipHostFree(c->h_ctl);
@@ -622,6 +640,7 @@ int ov_ensure(lpr_tableau* t, bool second_buffer) {
     chk(hipMalloc(&c->b.zrow, (size_t)c->ld * D));
     chk(hipMalloc(&c->b.bvec, (size_t)2 * c->Rp * D));
     chk(hipMalloc(&c->b.zparts, (size_t)2 * kOvGroups * sizeof(ZPart)));
+    chk(hipMalloc(&c->b.rparts, (size_t)(3 * kOvGroups + 1) * sizeof(double)));
     chk(hipMalloc(&c->b.ctl, 2 * sizeof(OvCtl)));
     chk(hipMalloc(&c->b.bar, 2 * sizeof(unsigned)));
     chk(hipHostMalloc(&c->h_ctl, 2 * sizeof(OvCtl)));
