@@ -53,6 +53,9 @@ int ov_begin(lpr_tableau* t, int64_t iter, int64_t max_iter);
 int ov_set_log(lpr_tableau* t, int parity);
 void ov_launch_step(lpr_tableau* t, int K, int tr, int lp);
 void ov_launch_heads(lpr_tableau* t, int K);
+int ov2_begin(lpr_tableau* t);
+int ov2_launch_step(lpr_tableau* t, int K, int tr, int lp);
+int ov2_join(lpr_tableau* t);
 void ov_launch_sweep(lpr_tableau* t, int tr);
 int ov_poll(lpr_tableau* t, int parity, int32_t* status, int32_t* cur, int64_t* applied,
             int32_t* error);
@@ -326,7 +329,7 @@ static constexpr size_t kOverlapBytes = (size_t)300 << 20;
 static int block_size(const lpr_tableau* t, const lpr_solve_opts& o) {
     // a specific one-pivot update-kernel variant was asked for (0x60tr = this path, tile rows tr)
     if (o.variant != 0 && (o.variant & 0xff00) != 0x6000 && (o.variant & 0xff00) != 0x5000 &&
-        (o.variant & 0xff00) != 0x4000)
+        (o.variant & 0xff00) != 0x4000 && (o.variant & 0xff00) != 0x3000)
         return 1;
     int k = o.block;
     if (k == 0) k = kDefaultBlock;
@@ -440,7 +443,7 @@ static int solve_blocked(lpr_tableau* t, const lpr_solve_opts& o, int K, lpr_sol
 // Large tableaux, default: K pivots per sweep with the next block's loop heads running inside the
 // same launch as the current block's (out-of-place) sweep -- overlap_kernels.hip.
 static int solve_overlapped(lpr_tableau* t, const lpr_solve_opts& o, int K, int tr, bool overlap,
-                            lpr_solve_result* res) {
+                            bool two_streams, lpr_solve_result* res) {
     lpr_engine* e = t->eng;
     hipStream_t s = e->stream;
     int rc = ov_ensure(t, overlap);
@@ -453,6 +456,10 @@ static int solve_overlapped(lpr_tableau* t, const lpr_solve_opts& o, int K, int 
     const int64_t max_iter = o.max_pivots > 0 ? start_iter + o.max_pivots : 0;
     rc = ov_begin(t, start_iter, max_iter);
     if (rc != LPR_OK_OPTIMAL) return rc;
+    if (two_streams) {
+        rc = ov2_begin(t);
+        if (rc != LPR_OK_OPTIMAL) return rc;
+    }
 
     int32_t status = kRunning, cur = 0, error = 0;
     int64_t applied = start_iter;
@@ -483,11 +490,30 @@ static int solve_overlapped(lpr_tableau* t, const lpr_solve_opts& o, int K, int 
         }
         for (int k = 0; k < nb; ++k) {
             const bool sample = timed && (k % kTimeStride) == 0;
+            if (two_streams) {
+                if (sample) {  // the step starts when both kernels of the previous one are done
+                    rc = ov2_join(t);
+                    if (rc != LPR_OK_OPTIMAL) return rc;
+                    LPR_HIP(hipEventRecord(t->ev[2 * k], s));
+                }
+                rc = ov2_launch_step(t, K, tr, k & 1);
+                if (rc != LPR_OK_OPTIMAL) return rc;
+                if (sample) {  // ... and ends when both of its kernels are
+                    rc = ov2_join(t);
+                    if (rc != LPR_OK_OPTIMAL) return rc;
+                    LPR_HIP(hipEventRecord(t->ev[2 * k + 1], s));
+                }
+                continue;
+            }
             if (!overlap) ov_launch_heads(t, K);
             if (sample) LPR_HIP(hipEventRecord(t->ev[2 * k], s));
             if (overlap) ov_launch_step(t, K, tr, k & 1);
             else ov_launch_sweep(t, tr);
             if (sample) LPR_HIP(hipEventRecord(t->ev[2 * k + 1], s));
+        }
+        if (two_streams) {
+            rc = ov2_join(t);
+            if (rc != LPR_OK_OPTIMAL) return rc;
         }
         LPR_HIP(hipGetLastError());
         int64_t now = applied;
@@ -783,11 +809,13 @@ int lpr_primal_solve(lpr_tableau* t, const lpr_solve_opts* opts, lpr_solve_resul
             // measured (tools/size_sweep.sh): up to ~230 MB the heads-then-sweep form is faster
             // (14-22 us per pivot), above it hiding the sweep behind the next heads wins
             const size_t tbytes = (size_t)t->rows * t->ld * sizeof(double);
-            bool overlap = (o.variant & 0xff00) == 0x5000 ||
-                           ((o.variant & 0xff00) == 0 && tbytes > kOverlapBytes);
+            // above kOverlapBytes the default is the two-stream form of the overlap (0x30tr)
+            const bool big = (o.variant & 0xff00) == 0 && tbytes > kOverlapBytes;
+            const bool two_streams = (o.variant & 0xff00) == 0x3000 || big;
+            bool overlap = two_streams || (o.variant & 0xff00) == 0x5000;
             const int tr = (o.variant & 0xff00) ? (o.variant & 0xff) : 8;
             if (overlap && ov_ensure(t, true) == LPR_OUT_OF_MEMORY) overlap = false;
-            return solve_overlapped(t, o, K, tr, overlap, res);
+            return solve_overlapped(t, o, K, tr, overlap, two_streams && overlap, res);
         }
     }
     const int variant = (o.variant > 0 && o.variant < 0x7000) ? o.variant - 1 : default_variant(t);

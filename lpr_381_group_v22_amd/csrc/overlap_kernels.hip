@@ -469,6 +469,409 @@ __device__ void ov_heads(const OvBuffers B, int ld, int R, int C, int Rp, int K,
 }
 
 // ------------------------------------------------------------------------------------------
+// The heads again, for the launches where they have a kernel (and so a register file) of their
+// own (k_ov_heads, k_ov2_heads).  Same protocol and arithmetic as ov_heads; what differs is where
+// the operands live.  A lane owns one row (gather / RHS) and one column pair (pivot row / Z row),
+// and everything that belongs to them stays in registers for the whole launch:
+//   fA / pA   its slices of the block being swept (the same for every pivot of the launch)
+//   myf / myp its slices of this block's own pivots so far (it computed them itself)
+//   myz, myb  its Z-row pair and RHS entry after the pivots staged so far
+// so a head needs three dependent memory trips -- the partial arg-mins; T[i, e] with the p_t[e];
+// after the barrier the ratio partials, then T[r, c] with the f_t[r] -- instead of about ten.
+// Lanes of very tall / wide tableaux own further rows / column pairs; those go through memory
+// (the loops marked "further").
+template <int NT>
+__device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, int K, int G, int lp,
+                              bool solo) {
+    __shared__ double lds_v[16];
+    __shared__ int lds_i[16];
+    __shared__ double lds_p[2];
+    __shared__ int s_r[kOvMax];   // rows of the pivots staged by this launch
+    __shared__ int rA[kOvMax];    // rows of the pivots of the block being swept
+    __shared__ double s_fa[kOvMax], s_fn[kOvMax];       // f_t[r] of the earlier pivots
+    __shared__ double s_pa[kOvMax], s_pn[kOvMax];       // p_t[e] of the earlier pivots
+    __shared__ double s_parhs[kOvMax], s_prhs[kOvMax];  // p_t[rhs]: block being swept / this block
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int g = blockIdx.x;
+    const bool lead = (g == 0);
+    const OvCtl* ci = B.ctl + lp;
+    OvCtl* co = B.ctl + (lp ^ 1);
+    const int32_t status = ci->status;
+    const int32_t pend_in = ci->pending;
+    const int kb = solo ? 0 : ci->kdone;
+    const int sa = ci->slot;
+    const int64_t staged0 = ci->staged;
+    const int64_t mx = ci->max_iter;
+    const int64_t log_cap = ci->log_cap;
+    const double* __restrict__ Tin = B.Tb[ci->cur];
+    const int ld2 = ld >> 1;
+    const int rhs = C - 1;
+    const size_t slotP = (size_t)kOvMax * ld, slotF = (size_t)kOvMax * Rp;
+    double* prowA = B.prow + (size_t)sa * slotP;
+    double* fcolA = B.fcol + (size_t)sa * slotF;
+    double* prowN = B.prow + (size_t)(sa ^ 1) * slotP;
+    double* fcolN = B.fcol + (size_t)(sa ^ 1) * slotF;
+    unsigned* bar = B.bar + lp;
+    const double2* Tin2 = reinterpret_cast<const double2*>(Tin);
+    const double2* prowA2 = reinterpret_cast<const double2*>(prowA);
+    double2* zrow2 = reinterpret_cast<double2*>(B.zrow);
+
+    const int i_first = g * nt + tid, c2_first = g * nt + tid;
+    const bool have_i = i_first < R, have_c = c2_first < ld2;
+    double fA[kOvMax], myf[kOvMax];
+    double2 pA[kOvMax], myp[kOvMax];
+#pragma unroll
+    for (int t = 0; t < kOvMax; ++t) {
+        fA[t] = (t < kb && have_i) ? fcolA[(size_t)t * Rp + i_first] : 0.0;
+        pA[t] = (t < kb && have_c) ? prowA2[(size_t)t * ld2 + c2_first] : make_double2(0.0, 0.0);
+        myf[t] = 0.0;
+        myp[t] = make_double2(0.0, 0.0);
+    }
+    double2 myz = have_c ? zrow2[c2_first] : make_double2(0.0, 0.0);
+    double myb = have_i ? B.bvec[(size_t)(staged0 & 1) * Rp + i_first] : 0.0;
+    if (tid < kOvMax) {
+        rA[tid] = (tid < kb) ? ci->r[tid] : -1;
+        s_parhs[tid] = (tid < kb) ? prowA[(size_t)tid * ld + rhs] : 0.0;
+    }
+    __syncthreads();
+
+    int32_t pend_out = pend_in;
+    int32_t status_out = status;
+    int count = 0;
+    int err = 0;
+    unsigned nbar = 0;
+
+    if (status == kRunning && pend_in != kRunning) {
+        status_out = pend_in;  // the block staged before is being swept by this very launch
+    } else if (status == kRunning) {
+        for (int q = 1; q <= K; ++q) {
+            const int64_t pidx = staged0 + q - 1;
+            const ZPart* bank_in = B.zparts + (pidx & 1) * kOvGroups;
+            ZPart* bank_out = B.zparts + ((pidx + 1) & 1) * kOvGroups;
+            const double* bprev = B.bvec + (size_t)(pidx & 1) * Rp;
+            double* bnew = B.bvec + (size_t)((pidx + 1) & 1) * Rp;
+            double* colq = fcolN + (size_t)(q - 1) * Rp;
+
+            // ---- entering column (:152-167) from the partials of the previous head ----
+            const int e = ov_reduce_zparts(bank_in, G).i;
+            if (e < 0) {
+                pend_out = LPR_OK_OPTIMAL;
+                break;
+            }
+            // ---- column e after all earlier pivots, this lane's row(s); one trip ----
+            double cq = have_i ? Tin[(size_t)i_first * ld + e] : 0.0;
+            if (tid < kb) s_pa[tid] = prowA[(size_t)tid * ld + e];
+            if (tid >= 32 && tid - 32 < q - 1) s_pn[tid - 32] = xld(&prowN[(size_t)(tid - 32) * ld + e]);
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < kOvMax; ++t) {  // through the block being swept
+                if (t < kb) {
+                    if (i_first == rA[t]) {
+                        cq = s_pa[t];
+                    } else {
+                        const double prod = fA[t] * s_pa[t];
+                        cq = cq - prod;
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < kOvMax; ++t) {  // through this block's earlier pivots
+                if (t < q - 1) {
+                    if (i_first == s_r[t]) {
+                        cq = s_pn[t];
+                    } else {
+                        const double prod = myf[t] * s_pn[t];
+                        cq = cq - prod;
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < kOvMax; ++t)
+                if (t == q - 1) myf[t] = cq;
+            // FindLeavingVariable (:169-191) on this lane's rows
+            Cand rc;
+            rc.v = DBL_MAX;
+            rc.i = -1;
+            double a_of_best = 0.0;
+            if (have_i) {
+                xst(&colq[i_first], cq);
+                if (i_first == 0) xst(&B.rparts[3 * kOvGroups], cq);  // T[0, e]
+                if (i_first >= 1 && cq > 1e-9) {
+                    const double ratio = myb / cq;
+                    if (ratio >= 0) {
+                        rc.v = ratio;
+                        rc.i = i_first;
+                        a_of_best = cq;
+                    }
+                }
+            }
+            for (int i = i_first + G * nt; i < R; i += G * nt) {  // further rows of this lane
+                double c = Tin[(size_t)i * ld + e];
+                for (int t = 0; t < kb; ++t) {
+                    if (i == rA[t]) {
+                        c = s_pa[t];
+                    } else {
+                        const double prod = fcolA[(size_t)t * Rp + i] * s_pa[t];
+                        c = c - prod;
+                    }
+                }
+                for (int t = 0; t < q - 1; ++t) {
+                    if (i == s_r[t]) {
+                        c = s_pn[t];
+                    } else {
+                        const double prod = fcolN[(size_t)t * Rp + i] * s_pn[t];
+                        c = c - prod;
+                    }
+                }
+                xst(&colq[i], c);
+                if (c > 1e-9) {
+                    const double ratio = bprev[i] / c;
+                    if (ratio >= 0 && ratio < rc.v) {
+                        rc.v = ratio;
+                        rc.i = i;
+                        a_of_best = c;
+                    }
+                }
+            }
+            {   // this workgroup's (ratio, row) minimum and its pivot element -> the partials
+                const int my_best = rc.i;
+                rc = block_cand_min(rc, lds_v, lds_i);
+                if (rc.i >= 0 && my_best == rc.i) lds_p[0] = a_of_best;
+                __syncthreads();
+                if (tid == 0) {
+                    xst(&B.rparts[g], rc.v);
+                    xst(&B.rparts[kOvGroups + g], rc.i >= 0 ? lds_p[0] : 0.0);
+                    xst(&B.rparts[2 * kOvGroups + g], (double)rc.i);
+                }
+            }
+            if (!ov_barrier(bar, (++nbar) * (unsigned)G)) {
+                err = 1;
+                break;
+            }
+
+            // ---- the leaving row: lexicographic minimum of the G partials ----
+            double p, f0;
+            int r;
+            {
+                const int lane = tid & (kWave - 1);
+                Cand c;
+                c.v = DBL_MAX;
+                c.i = -1;
+                double a = 0.0;
+                if (lane < G) {
+                    c.v = xld(&B.rparts[lane]);
+                    a = xld(&B.rparts[kOvGroups + lane]);
+                    c.i = (int)xld(&B.rparts[2 * kOvGroups + lane]);
+                }
+                f0 = xld(&B.rparts[3 * kOvGroups]);
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    Cand o;
+                    o.v = __shfl_xor(c.v, off, kWave);
+                    o.i = __shfl_xor(c.i, off, kWave);
+                    const double oa = __shfl_xor(a, off, kWave);
+                    const Cand m = cand_min(c, o);
+                    if (m.i != c.i || m.v != c.v) a = oa;
+                    c = m;
+                }
+                r = c.i;
+                p = a;
+            }
+            if (r < 0) {
+                pend_out = LPR_UNBOUNDED;
+                break;
+            }
+            if (mx > 0 && pidx >= mx) {
+                pend_out = LPR_PIVOT_LIMIT;
+                break;
+            }
+            if (tid == 0) s_r[q - 1] = r;
+
+            // ---- row r after all earlier pivots, normalised (:199); next Z row; one trip ----
+            double2 w = have_c ? Tin2[(size_t)r * ld2 + c2_first] : make_double2(0.0, 0.0);
+            if (tid < kb) s_fa[tid] = fcolA[(size_t)tid * Rp + r];
+            if (tid >= 32 && tid - 32 < q - 1) s_fn[tid - 32] = xld(&fcolN[(size_t)(tid - 32) * Rp + r]);
+            double wr = (tid == 128) ? Tin[(size_t)r * ld + rhs] : 0.0;
+            __syncthreads();
+            Cand n;
+            n.v = 0.0;
+            n.i = -1;
+            if (have_c) {
+#pragma unroll
+                for (int t = 0; t < kOvMax; ++t) {
+                    if (t < kb) {
+                        if (r == rA[t]) {
+                            w = pA[t];
+                        } else {
+                            const double f = s_fa[t];
+                            const double px = f * pA[t].x;
+                            const double py = f * pA[t].y;
+                            w.x = w.x - px;
+                            w.y = w.y - py;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < kOvMax; ++t) {
+                    if (t < q - 1) {
+                        if (r == s_r[t]) {
+                            w = myp[t];
+                        } else {
+                            const double f = s_fn[t];
+                            const double px = f * myp[t].x;
+                            const double py = f * myp[t].y;
+                            w.x = w.x - px;
+                            w.y = w.y - py;
+                        }
+                    }
+                }
+                const int j = 2 * c2_first;
+                double2 pq;
+                pq.x = (j < C) ? w.x / p : 0.0;  // :199 true division
+                pq.y = (j + 1 < C) ? w.y / p : 0.0;
+#pragma unroll
+                for (int t = 0; t < kOvMax; ++t)
+                    if (t == q - 1) myp[t] = pq;
+                xst(&prowN[(size_t)(q - 1) * ld + j], pq.x);
+                xst(&prowN[(size_t)(q - 1) * ld + j + 1], pq.y);
+                const double mxp = f0 * pq.x;  // :208 product rounded, then the difference
+                const double myp2 = f0 * pq.y;
+                myz.x = myz.x - mxp;
+                myz.y = myz.y - myp2;
+                zrow2[c2_first] = myz;  // read again by the next launch
+                if (j < C - 1 && myz.x < n.v) {
+                    n.v = myz.x;
+                    n.i = j;
+                }
+                if (j + 1 < C - 1 && myz.y < n.v) {
+                    n.v = myz.y;
+                    n.i = j + 1;
+                }
+            }
+            for (int c2 = c2_first + G * nt; c2 < ld2; c2 += G * nt) {  // further column pairs
+                double2 ww = Tin2[(size_t)r * ld2 + c2];
+                double2 z = zrow2[c2];
+                for (int t = 0; t < kb; ++t) {
+                    const double2 ps = prowA2[(size_t)t * ld2 + c2];
+                    if (r == rA[t]) {
+                        ww = ps;
+                    } else {
+                        const double f = s_fa[t];
+                        const double px = f * ps.x;
+                        const double py = f * ps.y;
+                        ww.x = ww.x - px;
+                        ww.y = ww.y - py;
+                    }
+                }
+                for (int t = 0; t < q - 1; ++t) {
+                    double2 ps;
+                    ps.x = prowN[(size_t)t * ld + 2 * c2];
+                    ps.y = prowN[(size_t)t * ld + 2 * c2 + 1];
+                    if (r == s_r[t]) {
+                        ww = ps;
+                    } else {
+                        const double f = s_fn[t];
+                        const double px = f * ps.x;
+                        const double py = f * ps.y;
+                        ww.x = ww.x - px;
+                        ww.y = ww.y - py;
+                    }
+                }
+                const int j = 2 * c2;
+                double2 pq;
+                pq.x = (j < C) ? ww.x / p : 0.0;
+                pq.y = (j + 1 < C) ? ww.y / p : 0.0;
+                xst(&prowN[(size_t)(q - 1) * ld + j], pq.x);
+                xst(&prowN[(size_t)(q - 1) * ld + j + 1], pq.y);
+                const double mxp = f0 * pq.x;
+                const double myp2 = f0 * pq.y;
+                z.x = z.x - mxp;
+                z.y = z.y - myp2;
+                zrow2[c2] = z;
+                if (j < C - 1 && z.x < n.v) {
+                    n.v = z.x;
+                    n.i = j;
+                }
+                if (j + 1 < C - 1 && z.y < n.v) {
+                    n.v = z.y;
+                    n.i = j + 1;
+                }
+            }
+            n = block_cand_min(n, lds_v, lds_i);
+
+            // ---- RHS column after this pivot ----
+            if (tid == 128) {
+                for (int t = 0; t < kb; ++t) {
+                    if (r == rA[t]) {
+                        wr = s_parhs[t];
+                    } else {
+                        const double prod = s_fa[t] * s_parhs[t];
+                        wr = wr - prod;
+                    }
+                }
+                for (int t = 0; t < q - 1; ++t) {
+                    if (r == s_r[t]) {
+                        wr = s_prhs[t];
+                    } else {
+                        const double prod = s_fn[t] * s_prhs[t];
+                        wr = wr - prod;
+                    }
+                }
+                const double v = wr / p;
+                s_prhs[q - 1] = v;  // p_q[rhs]: every workgroup works it out for itself
+                lds_p[1] = v;
+            }
+            __syncthreads();
+            const double prhs = lds_p[1];
+            if (have_i) {
+                const double prod = cq * prhs;
+                myb = (i_first == r) ? prhs : myb - prod;
+                xst(&bnew[i_first], myb);
+            }
+            for (int i = i_first + G * nt; i < R; i += G * nt) {  // further rows of this lane
+                const double prod = colq[i] * prhs;
+                xst(&bnew[i], (i == r) ? prhs : bprev[i] - prod);
+            }
+            if (tid == 0) {
+                xst(&bank_out[g].v, n.v);
+                xst(&bank_out[g].i, n.i);
+                if (lead) {
+                    co->r[q - 1] = r;
+                    B.basis[r - 1] = e;  // :142
+                    if (pidx < log_cap) {
+                        B.log[2 * pidx] = r;
+                        B.log[2 * pidx + 1] = e;
+                    }
+                }
+            }
+            count = q;
+            if (!ov_barrier(bar, (++nbar) * (unsigned)G)) {
+                err = 1;
+                break;
+            }
+        }
+    }
+
+    if (lead && tid == 0) {  // the next launch's view (fields owned by the heads)
+        const bool staged_now = (status == kRunning && pend_in == kRunning);
+        co->status = err ? LPR_DEVICE_ERROR : status_out;
+        co->pending = pend_out;
+        co->kdone = staged_now ? count : 0;
+        co->slot = staged_now ? (sa ^ 1) : sa;
+        co->staged = staged0 + (staged_now ? count : 0);
+        co->max_iter = mx;
+        co->log_cap = log_cap;
+        co->error = err | ci->error;
+        B.bar[lp ^ 1] = 0u;
+        if (solo) {
+            co->applied = ci->applied;
+            co->cur = ci->cur;
+            co->sweep = ci->sweep;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // The sweep of the current block (workgroups [G, ...)): every element through kdone pivots
 // (:202-210 each) in registers, buffer cur -> buffer cur ^ 1.
 template <int TR, bool INPLACE>
@@ -573,13 +976,28 @@ __global__ __launch_bounds__(kOvNT) void k_ov_step(const OvBuffers B, int ld, in
         ov_tiles<TR, false>(B, ld, R, Rp, G, lp);
 }
 
+// The two halves as separate kernels on two streams, running concurrently (variant 0x30tr): same
+// protocol as k_ov_step, but each kernel has its own register budget (in k_ov_step the heads'
+// registers cap the occupancy of the sweep's tiles and vice versa).
+template <int NT>
+__global__ __launch_bounds__(NT) void k_ov2_heads(const OvBuffers B, int ld, int R, int C, int Rp,
+                                                  int K, int G, int lp) {
+    ov_heads_rich<NT>(B, ld, R, C, Rp, K, G, lp, false);
+}
+
+template <int TR>
+__global__ __launch_bounds__(kOvNT) void k_ov2_sweep(const OvBuffers B, int ld, int R, int Rp,
+                                                     int lp) {
+    ov_tiles<TR, false>(B, ld, R, Rp, 0, lp);
+}
+
 // The same two halves as separate launches: all K loop heads of a block in ONE persistent launch
 // (no sweep running: nothing to chain through but the block's own pivots), then the sweep in
 // place.  Heads always run on control block 0, the sweep on control block 1.
 template <int NT>
 __global__ __launch_bounds__(NT) void k_ov_heads(const OvBuffers B, int ld, int R, int C, int Rp,
                                                  int K, int G) {
-    ov_heads<NT>(B, ld, R, C, Rp, K, G, 0, true);
+    ov_heads_rich<NT>(B, ld, R, C, Rp, K, G, 0, true);
 }
 
 template <int TR>
@@ -597,6 +1015,9 @@ struct lpr_overlap_ctx {
     lpr::OvBuffers b{};
     lpr::OvCtl* h_ctl = nullptr;  // pinned, 2 entries
     double* T2 = nullptr;         // the second tableau buffer (owned here)
+    hipStream_t hstream = nullptr;  // the heads' stream of the two-stream variant
+    hipEvent_t ev_h[2] = {nullptr, nullptr}, ev_s[2] = {nullptr, nullptr};
+    int ev_idx = 0;
 };
 
 namespace lpr {
@@ -606,6 +1027,14 @@ int ov_max_pivots() { return kOvMax; }
 void ov_release(lpr_tableau* t) {
     lpr_overlap_ctx* c = static_cast<lpr_overlap_ctx*>(t->ov);
     if (!c) return;
+    if (c->hstream) {
+        hipStreamSynchronize(c->hstream);
+        hipStreamDestroy(c->hstream);
+        for (int k = 0; k < 2; ++k) {
+            hipEventDestroy(c->ev_h[k]);
+            hipEventDestroy(c->ev_s[k]);
+        }
+    }
     hipFree(c->T2);
     hipFree(c->b.prow);
     hipFree(c->b.fcol);
@@ -729,15 +1158,8 @@ void ov_launch_heads(lpr_tableau* t, int K) {
     if (G < 1) G = 1;
     if (G > kOvGroups) G = kOvGroups;
     hipStream_t s = t->eng->stream;
-    if (nt >= 1024)
-        hipLaunchKernelGGL((k_ov_heads<1024>), dim3(G), dim3(1024), 0, s, c->b, t->ld, t->rows,
-                           t->cols, c->Rp, K, G);
-    else if (nt >= 512)
-        hipLaunchKernelGGL((k_ov_heads<512>), dim3(G), dim3(512), 0, s, c->b, t->ld, t->rows,
-                           t->cols, c->Rp, K, G);
-    else
-        hipLaunchKernelGGL((k_ov_heads<256>), dim3(G), dim3(256), 0, s, c->b, t->ld, t->rows,
-                           t->cols, c->Rp, K, G);
+    hipLaunchKernelGGL((k_ov_heads<kOvNT>), dim3(G), dim3(kOvNT), 0, s, c->b, t->ld, t->rows,
+                       t->cols, c->Rp, K, G);
 }
 
 void ov_launch_sweep(lpr_tableau* t, int tr) {
@@ -754,6 +1176,59 @@ void ov_launch_sweep(lpr_tableau* t, int tr) {
     else
         hipLaunchKernelGGL((k_ov_sweep<4>), dim3(nct * nrt), dim3(kOvNT), 0, s, c->b, t->ld,
                            t->rows, c->Rp);
+}
+
+// two-stream variant: heads on their own (high-priority) stream, sweep on the engine stream.
+// Step k's kernels both start when both kernels of step k-1 are done.
+int ov2_begin(lpr_tableau* t) {
+    lpr_overlap_ctx* c = static_cast<lpr_overlap_ctx*>(t->ov);
+    if (!c->hstream) {
+        int lo = 0, hi = 0;
+        LPR_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        LPR_HIP(hipStreamCreateWithPriority(&c->hstream, hipStreamNonBlocking, hi));
+        for (int k = 0; k < 2; ++k) {
+            LPR_HIP(hipEventCreateWithFlags(&c->ev_h[k], hipEventDisableTiming));
+            LPR_HIP(hipEventCreateWithFlags(&c->ev_s[k], hipEventDisableTiming));
+        }
+    }
+    // everything queued on the engine stream so far (prologue, control block) precedes step 0
+    c->ev_idx = 0;
+    LPR_HIP(hipEventRecord(c->ev_s[1], t->eng->stream));
+    LPR_HIP(hipEventRecord(c->ev_h[1], c->hstream));
+    return LPR_OK_OPTIMAL;
+}
+
+int ov2_launch_step(lpr_tableau* t, int K, int tr, int lp) {
+    lpr_overlap_ctx* c = static_cast<lpr_overlap_ctx*>(t->ov);
+    hipStream_t S = t->eng->stream, H = c->hstream;
+    const int cur = c->ev_idx, prev = cur ^ 1;
+    LPR_HIP(hipStreamWaitEvent(H, c->ev_s[prev], 0));
+    LPR_HIP(hipStreamWaitEvent(S, c->ev_h[prev], 0));
+    const int G = ov_groups(t);
+    hipLaunchKernelGGL((k_ov2_heads<kOvNT>), dim3(G), dim3(kOvNT), 0, H, c->b, t->ld, t->rows,
+                       t->cols, c->Rp, K, G, lp);
+    LPR_HIP(hipEventRecord(c->ev_h[cur], H));
+    const int nct = (t->ld / 2 + kOvNT - 1) / kOvNT;
+    const int nrt = (t->rows + kOvTileRows - 1) / kOvTileRows;
+    if (tr >= 16)
+        hipLaunchKernelGGL((k_ov2_sweep<16>), dim3(nct * nrt), dim3(kOvNT), 0, S, c->b, t->ld,
+                           t->rows, c->Rp, lp);
+    else if (tr >= 8)
+        hipLaunchKernelGGL((k_ov2_sweep<8>), dim3(nct * nrt), dim3(kOvNT), 0, S, c->b, t->ld,
+                           t->rows, c->Rp, lp);
+    else
+        hipLaunchKernelGGL((k_ov2_sweep<4>), dim3(nct * nrt), dim3(kOvNT), 0, S, c->b, t->ld,
+                           t->rows, c->Rp, lp);
+    LPR_HIP(hipEventRecord(c->ev_s[cur], S));
+    c->ev_idx = prev;
+    return LPR_OK_OPTIMAL;
+}
+
+// the engine stream catches up with the heads' stream (before a poll / the end of the call)
+int ov2_join(lpr_tableau* t) {
+    lpr_overlap_ctx* c = static_cast<lpr_overlap_ctx*>(t->ov);
+    LPR_HIP(hipStreamWaitEvent(t->eng->stream, c->ev_h[c->ev_idx ^ 1], 0));
+    return LPR_OK_OPTIMAL;
 }
 
 // reads control block `parity` back

@@ -3,7 +3,7 @@ O(R + C) data and applying them in one sweep must give the same status, pivot lo
 tableau BITS as the oracle's one-pivot-at-a-time loop, for every K, every stop reason and every
 way a pivot limit can cut a block.  Two implementations: csrc/overlap_kernels.hip (default on
 large tableaux: out-of-place sweep with the next block's loop heads inside the same launch,
-variant 0x50tr; and the default, variant 0x40tr: all loop heads of a block in one persistent
+variant 0x50tr; the same as two concurrent kernels on two streams, variant 0x30tr; and variant 0x40tr: all loop heads of a block in one persistent
 launch, then the sweep in place) and csrc/block_kernels.hip (in place, one launch per loop head,
 variant 0x60tr)."""
 import hashlib
@@ -15,10 +15,11 @@ import lp_cases
 
 pytestmark = pytest.mark.gpu
 
-SEQ, OV, INPLACE = 0x4008, 0x5008, 0x6008
-NAMES = {SEQ: "seq", OV: "ov", INPLACE: "inplace"}
+SEQ, OV, INPLACE, OV2 = 0x4008, 0x5008, 0x6008, 0x3008
+NAMES = {SEQ: "seq", OV: "ov", INPLACE: "inplace", OV2: "ov2"}
 # (variant, block)
 BLOCKS = [(SEQ, 2), (SEQ, 5), (SEQ, 8), (SEQ, 16), (OV, 2), (OV, 3), (OV, 8), (OV, 16),
+          (OV2, 2), (OV2, 7), (OV2, 16),
           (INPLACE, 2), (INPLACE, 4), (INPLACE, 8)]
 IDS = [NAMES[v] + str(b) for v, b in BLOCKS]
 
@@ -89,7 +90,7 @@ def test_resume_after_pivot_limit(engine, oracle, variant, block):
     tab.destroy()
 
 
-@pytest.mark.parametrize("variant,block,timed", [(SEQ, 3, False), (SEQ, 16, True), (OV, 2, False), (OV, 4, True), (OV, 16, False),
+@pytest.mark.parametrize("variant,block,timed", [(SEQ, 3, False), (SEQ, 16, True), (OV2, 16, False), (OV2, 6, True), (OV, 2, False), (OV, 4, True), (OV, 16, False),
                                                  (OV, 11, True), (INPLACE, 8, False),
                                                  (INPLACE, 5, True)])
 def test_medium_dense_lp_full_solve(engine, oracle, variant, block, timed):
@@ -125,7 +126,7 @@ def test_sweep_tile_shapes_give_identical_bits(engine, oracle, base, tr):
     tab.destroy()
 
 
-@pytest.mark.parametrize("variant,block", [(SEQ, 8), (SEQ, 16), (OV, 8), (OV, 16), (INPLACE, 8)])
+@pytest.mark.parametrize("variant,block", [(SEQ, 8), (SEQ, 16), (OV, 8), (OV, 16), (OV2, 16), (INPLACE, 8)])
 def test_repeated_rows_and_columns_inside_a_block(engine, oracle, variant, block):
     """Degenerate / tie-heavy LPs: the same row leaves twice within one block, a column re-enters,
     ties in both arg-mins -- the chains through earlier pivots must reproduce them exactly."""
@@ -151,7 +152,7 @@ def test_repeated_rows_and_columns_inside_a_block(engine, oracle, variant, block
     assert seen_repeat and seen_col_repeat, "fixtures no longer repeat a pivot row / column inside a block"
 
 
-@pytest.mark.parametrize("variant", [SEQ, OV, INPLACE])
+@pytest.mark.parametrize("variant", [SEQ, OV, OV2, INPLACE])
 def test_wide_and_tall_shapes(engine, oracle, variant):
     """ld wider than one head trip (G * 256 double2 < ld / 2) and tall thin tableaux."""
     from lpr_381_group_v22_amd import Tableau
