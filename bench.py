@@ -165,9 +165,10 @@ def run_primal(args, D: Dist):
                 kname = (f"sweep of {block} pivots (each element read once, taken through "
                          f"{block} rounded multiply-subtract steps in registers, written once)")
             else:
-                kname = (f"k_ov_step: sweep of {block} pivots (each element read once, taken "
+                kname = (f"k_ov2_sweep: sweep of {block} pivots (each element read once, taken "
                          f"through {block} rounded multiply-subtract steps in registers, written "
-                         f"once) with the loop heads of the next {block} pivots in the same launch")
+                         f"once), timed together with k_ov2_heads, the loop heads of the next "
+                         f"{block} pivots, which runs concurrently on a second stream")
             roof = {"bound": "hbm", "kernel": kname,
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 4),
@@ -190,7 +191,7 @@ def run_primal(args, D: Dist):
                     "achieved/frac follow the contract (algorithmic bytes of the pivots one launch "
                     "applies / launch time) and exceed the HBM peak because the sweep moves each "
                     "element once for all its pivots; hbm_side_frac is the physical traffic "
-                    "(PMC) / launch time / peak.  The launch lasts as long as its loop heads "
+                    "(PMC) / launch time / peak.  A step lasts as long as its loop heads "
                     "(latency-bound, O(R+C) data per pivot), not as long as its sweep.")
         cpu = None
         if D.world == 1 and args.cpu_pivots != 0:

@@ -940,7 +940,16 @@ __device__ void ov_tiles(const OvBuffers B, int ld, int R, int Rp, int G, int lp
 #pragma unroll
         for (int k = 0; k < TR; ++k) {
             const int i = i0 + k;
-            if (i < iend) x[k] = Tin2[(size_t)i * ld2 + c2];
+            if (i < iend) {
+                if (INPLACE) {
+                    x[k] = Tin2[(size_t)i * ld2 + c2];
+                } else {  // streamed once: keep it out of the caches the heads live in
+                    typedef double v2d __attribute__((ext_vector_type(2)));
+                    const v2d v = __builtin_nontemporal_load(
+                        reinterpret_cast<const v2d*>(&Tin2[(size_t)i * ld2 + c2]));
+                    x[k] = make_double2(v.x, v.y);
+                }
+            }
         }
 #pragma unroll
         for (int k = 0; k < TR; ++k) {
@@ -961,7 +970,15 @@ __device__ void ov_tiles(const OvBuffers B, int ld, int R, int Rp, int G, int lp
                         }
                     }
                 }
-                Tout2[(size_t)i * ld2 + c2] = t;
+                if (INPLACE) {
+                    Tout2[(size_t)i * ld2 + c2] = t;
+                } else {
+                    typedef double v2d __attribute__((ext_vector_type(2)));
+                    v2d v;
+                    v.x = t.x;
+                    v.y = t.y;
+                    __builtin_nontemporal_store(v, reinterpret_cast<v2d*>(&Tout2[(size_t)i * ld2 + c2]));
+                }
             }
         }
     }
