@@ -1,18 +1,23 @@
-// overlap_kernels.hip -- the large-tableau primal path: K pivots per sweep, with the decisions for
-// the NEXT K pivots made while the sweep of the current K is running.
+// overlap_kernels.hip -- the primal path of tableaux above 12 MB: K pivots per sweep, decided by
+// persistent "loop head" workgroups; on the largest tableaux the heads of the NEXT K pivots run
+// while the sweep of the current K is running.
 // (reference: LPR_381_Group_V22/Simplex/PrimalSimplexSolver.cs:102-211)
 //
 // block_kernels.hip explains why K pivots can be decided from O(R + C) data each and then applied
-// to every element in one sweep with bit-identical results.  Here the sweep is out of place
-// (tableau buffer `cur` -> buffer `cur ^ 1`), so while it runs, the buffer it reads is still the
-// tableau BEFORE the block -- and the loop heads of the next block can work from that very
-// buffer, taking every column / row they fetch through the block being swept plus their own
-// earlier pivots.  One launch of k_ov_step therefore contains
-//   * workgroups [0, G): the heads of block B+1, a persistent loop over its pivots with a
-//     spin barrier between the phases (gather the entering column | ratio test, normalise the
-//     row, next Z row).  They are dispatched first, so all G are resident when they meet.
-//   * the remaining workgroups: the sweep of block B, TR x 256-double2 tiles.
-// and a launch lasts max(sweep, heads).  Per pivot the tableau moves 2*8*R*C / K bytes.
+// to every element in one sweep with bit-identical results.  The pieces here:
+//   ov_heads / ov_heads_rich   the K loop heads of a block as ONE persistent group of G workgroups
+//                              with a spin barrier between the two phases of a head.
+//   ov_tiles                   the sweep: 32-row x 256-double2 tiles.
+// and three ways of putting them on the device (lpr_engine.hip picks by tableau size):
+//   k_ov_heads + k_ov_sweep    heads, then the sweep in place (0x40tr; 12 MB .. 300 MB).
+//   k_ov2_heads || k_ov2_sweep two kernels on two streams (0x30tr; above 300 MB): the sweep is out
+//                              of place (tableau buffer `cur` -> `cur ^ 1`), so while it runs the
+//                              buffer it reads is still the tableau BEFORE the block, and the heads
+//                              of the next block work from that very buffer, taking every column /
+//                              row they fetch through the block being swept plus their own earlier
+//                              pivots.  A step lasts max(sweep, heads).
+//   k_ov_step                  the same overlap in one launch (0x50tr): workgroups [0, G) are the
+//                              heads -- dispatched first, so resident together -- the rest sweep.
 //
 // Control state that a launch both reads and updates exists twice (`OvCtl ctl[2]`): the launch
 // with parity p reads ctl[p] and its two lead workgroups write ctl[p ^ 1] -- so no workgroup can
