@@ -156,7 +156,8 @@ def test_repeated_rows_and_columns_inside_a_block(engine, oracle, variant, block
 def test_wide_and_tall_shapes(engine, oracle, variant):
     """ld wider than one head trip (G * 256 double2 < ld / 2) and tall thin tableaux."""
     from lpr_381_group_v22_amd import Tableau
-    for (m, n, seed) in [(6, 20000, 1), (3000, 10, 2), (2, 5000, 4), (1, 1, 3)]:
+    # (3, 40000): more column pairs than head lanes (64 groups x 256): the lanes' "further" loops
+    for (m, n, seed) in [(6, 20000, 1), (3000, 10, 2), (2, 5000, 4), (1, 1, 3), (3, 40000, 6)]:
         T, basis = oracle.gen_dense_tableau(m, n, seed)
         st, piv, log = oracle.primal_solve(T, basis, 600)
         tab = Tableau.synthetic(engine, m, n, seed)
