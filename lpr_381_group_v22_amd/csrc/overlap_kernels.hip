@@ -62,7 +62,7 @@ struct OvBuffers {      // everything the step kernel touches, passed by value
     ZPart* zparts;      // [2][kOvGroups]
     double* rparts;     // [3][kOvGroups] ratio-test partials: ratio, pivot element, row (as double); + f0
     OvCtl* ctl;         // [2]
-    unsigned* bar;      // [2]
+    unsigned* bar;      // [2], then [2] = head workgroups that have started (two-stream form)
     int32_t* basis;
     int32_t* log;
 };
@@ -1001,10 +1001,26 @@ __global__ __launch_bounds__(kOvNT) void k_ov_step(const OvBuffers B, int ld, in
 // The two halves as separate kernels on two streams, running concurrently (variant 0x30tr): same
 // protocol as k_ov_step, but each kernel has its own register budget (in k_ov_step the heads'
 // registers cap the occupancy of the sweep's tiles and vice versa).
+// The heads take their CUs for themselves: launched with (almost) a CU's whole LDS as dynamic
+// shared memory, so no tile workgroup (which needs LDS too) can be placed beside them.  What a
+// hand-off between workgroups costs is queueing in the CONSUMER CU's own memory pipeline: beside
+// twelve streaming tile waves a round trip took 2.5-3 us, on a CU of its own about half.
+// k_ov2_gate holds the sweep back until all G head workgroups are resident.
 template <int NT>
 __global__ __launch_bounds__(NT) void k_ov2_heads(const OvBuffers B, int ld, int R, int C, int Rp,
                                                   int K, int G, int lp) {
+    if (threadIdx.x == 0)
+        __hip_atomic_fetch_add(B.bar + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     ov_heads_rich<NT>(B, ld, R, C, Rp, K, G, lp, false);
+}
+
+__global__ __launch_bounds__(64) void k_ov2_gate(const unsigned* started, unsigned target) {
+    if (threadIdx.x != 0) return;
+    unsigned spins = 0;
+    while (__hip_atomic_load(started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > kOvSpinMax) break;  // never hold the sweep back for good
+    }
 }
 
 template <int TR>
@@ -1040,6 +1056,8 @@ struct lpr_overlap_ctx {
     hipStream_t hstream = nullptr;  // the heads' stream of the two-stream variant
     hipEvent_t ev_h[2] = {nullptr, nullptr}, ev_s[2] = {nullptr, nullptr};
     int ev_idx = 0;
+    unsigned steps = 0;          // two-stream steps launched since ov2_begin
+    int heads_lds = 0;           // dynamic LDS of k_ov2_heads (0: could not be raised)
 };
 
 namespace lpr {
@@ -1093,7 +1111,7 @@ int ov_ensure(lpr_tableau* t, bool second_buffer) {
     chk(hipMalloc(&c->b.zparts, (size_t)2 * kOvGroups * sizeof(ZPart)));
     chk(hipMalloc(&c->b.rparts, (size_t)(3 * kOvGroups + 1) * sizeof(double)));
     chk(hipMalloc(&c->b.ctl, 2 * sizeof(OvCtl)));
-    chk(hipMalloc(&c->b.bar, 2 * sizeof(unsigned)));
+    chk(hipMalloc(&c->b.bar, 4 * sizeof(unsigned)));
     chk(hipHostMalloc(&c->h_ctl, 2 * sizeof(OvCtl)));
     t->ov = c;
     if (err != hipSuccess) {
@@ -1137,7 +1155,7 @@ int ov_begin(lpr_tableau* t, int64_t iter, int64_t max_iter) {
     h[0].log_cap = t->log_cap;
     h[1] = h[0];
     LPR_HIP(hipMemcpyAsync(c->b.ctl, h, 2 * sizeof(OvCtl), hipMemcpyHostToDevice, s));
-    LPR_HIP(hipMemsetAsync(c->b.bar, 0, 2 * sizeof(unsigned), s));
+    LPR_HIP(hipMemsetAsync(c->b.bar, 0, 4 * sizeof(unsigned), s));
     hipLaunchKernelGGL(k_ov_prologue, dim3(1), dim3(1024), 0, s, t->T, t->ld, t->rows, t->cols,
                        c->b.zrow, c->b.bvec + (size_t)(iter & 1) * c->Rp,
                        c->b.zparts + (iter & 1) * kOvGroups, ov_groups(t));
@@ -1213,8 +1231,18 @@ int ov2_begin(lpr_tableau* t) {
             LPR_HIP(hipEventCreateWithFlags(&c->ev_s[k], hipEventDisableTiming));
         }
     }
+    if (c->heads_lds == 0) {  // once: let the heads' launch ask for a CU's whole LDS
+        const int want = 150 * 1024;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ov2_heads<kOvNT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess)
+            c->heads_lds = want;
+        else
+            c->heads_lds = -1;
+        (void)hipGetLastError();
+    }
     // everything queued on the engine stream so far (prologue, control block) precedes step 0
     c->ev_idx = 0;
+    c->steps = 0;
     LPR_HIP(hipEventRecord(c->ev_s[1], t->eng->stream));
     LPR_HIP(hipEventRecord(c->ev_h[1], c->hstream));
     return LPR_OK_OPTIMAL;
@@ -1227,9 +1255,12 @@ int ov2_launch_step(lpr_tableau* t, int K, int tr, int lp) {
     LPR_HIP(hipStreamWaitEvent(H, c->ev_s[prev], 0));
     LPR_HIP(hipStreamWaitEvent(S, c->ev_h[prev], 0));
     const int G = ov_groups(t);
-    hipLaunchKernelGGL((k_ov2_heads<kOvNT>), dim3(G), dim3(kOvNT), 0, H, c->b, t->ld, t->rows,
-                       t->cols, c->Rp, K, G, lp);
+    hipLaunchKernelGGL((k_ov2_heads<kOvNT>), dim3(G), dim3(kOvNT),
+                       c->heads_lds > 0 ? c->heads_lds : 0, H, c->b, t->ld, t->rows, t->cols,
+                       c->Rp, K, G, lp);
     LPR_HIP(hipEventRecord(c->ev_h[cur], H));
+    c->steps += 1;
+    hipLaunchKernelGGL(k_ov2_gate, dim3(1), dim3(64), 0, S, c->b.bar + 2, c->steps * (unsigned)G);
     const int nct = (t->ld / 2 + kOvNT - 1) / kOvNT;
     const int nrt = (t->rows + kOvTileRows - 1) / kOvTileRows;
     if (tr >= 16)
