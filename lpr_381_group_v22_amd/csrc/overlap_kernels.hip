@@ -1001,11 +1001,10 @@ __global__ __launch_bounds__(kOvNT) void k_ov_step(const OvBuffers B, int ld, in
 // The two halves as separate kernels on two streams, running concurrently (variant 0x30tr): same
 // protocol as k_ov_step, but each kernel has its own register budget (in k_ov_step the heads'
 // registers cap the occupancy of the sweep's tiles and vice versa).
-// The heads take their CUs for themselves: launched with (almost) a CU's whole LDS as dynamic
-// shared memory, so no tile workgroup (which needs LDS too) can be placed beside them.  What a
-// hand-off between workgroups costs is queueing in the CONSUMER CU's own memory pipeline: beside
-// twelve streaming tile waves a round trip took 2.5-3 us, on a CU of its own about half.
-// k_ov2_gate holds the sweep back until all G head workgroups are resident.
+// k_ov2_gate holds the sweep back until all G head workgroups are resident (they announce
+// themselves), so the heads are never queued behind thousands of tile workgroups.  (Giving the
+// heads their CUs to themselves -- a 148 KB LDS claim that leaves tiles no room -- was measured
+// too: 7 % slower; what slows a head beside the sweep is not its own CU's memory queue.)
 template <int NT>
 __global__ __launch_bounds__(NT) void k_ov2_heads(const OvBuffers B, int ld, int R, int C, int Rp,
                                                   int K, int G, int lp) {
@@ -1057,7 +1056,6 @@ struct lpr_overlap_ctx {
     hipEvent_t ev_h[2] = {nullptr, nullptr}, ev_s[2] = {nullptr, nullptr};
     int ev_idx = 0;
     unsigned steps = 0;          // two-stream steps launched since ov2_begin
-    int heads_lds = 0;           // dynamic LDS of k_ov2_heads (0: could not be raised)
 };
 
 namespace lpr {
@@ -1231,15 +1229,6 @@ int ov2_begin(lpr_tableau* t) {
             LPR_HIP(hipEventCreateWithFlags(&c->ev_s[k], hipEventDisableTiming));
         }
     }
-    if (c->heads_lds == 0) {  // once: let the heads' launch ask for a CU's whole LDS
-        const int want = 150 * 1024;
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ov2_heads<kOvNT>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess)
-            c->heads_lds = want;
-        else
-            c->heads_lds = -1;
-        (void)hipGetLastError();
-    }
     // everything queued on the engine stream so far (prologue, control block) precedes step 0
     c->ev_idx = 0;
     c->steps = 0;
@@ -1255,9 +1244,8 @@ int ov2_launch_step(lpr_tableau* t, int K, int tr, int lp) {
     LPR_HIP(hipStreamWaitEvent(H, c->ev_s[prev], 0));
     LPR_HIP(hipStreamWaitEvent(S, c->ev_h[prev], 0));
     const int G = ov_groups(t);
-    hipLaunchKernelGGL((k_ov2_heads<kOvNT>), dim3(G), dim3(kOvNT),
-                       c->heads_lds > 0 ? c->heads_lds : 0, H, c->b, t->ld, t->rows, t->cols,
-                       c->Rp, K, G, lp);
+    hipLaunchKernelGGL((k_ov2_heads<kOvNT>), dim3(G), dim3(kOvNT), 0, H, c->b, t->ld, t->rows,
+                       t->cols, c->Rp, K, G, lp);
     LPR_HIP(hipEventRecord(c->ev_h[cur], H));
     c->steps += 1;
     hipLaunchKernelGGL(k_ov2_gate, dim3(1), dim3(64), 0, S, c->b.bar + 2, c->steps * (unsigned)G);
