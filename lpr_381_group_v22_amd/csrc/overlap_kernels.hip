@@ -62,7 +62,7 @@ struct OvBuffers {      // everything the step kernel touches, passed by value
     ZPart* zparts;      // [2][kOvGroups]
     double* rparts;     // [3][kOvGroups] ratio-test partials: ratio, pivot element, row (as double); + f0
     OvCtl* ctl;         // [2]
-    unsigned* bar;      // [2], then [2] = head workgroups that have started (two-stream form)
+    unsigned* bar;      // [2]
     int32_t* basis;
     int32_t* log;
 };
@@ -1001,25 +1001,10 @@ __global__ __launch_bounds__(kOvNT) void k_ov_step(const OvBuffers B, int ld, in
 // The two halves as separate kernels on two streams, running concurrently (variant 0x30tr): same
 // protocol as k_ov_step, but each kernel has its own register budget (in k_ov_step the heads'
 // registers cap the occupancy of the sweep's tiles and vice versa).
-// k_ov2_gate holds the sweep back until all G head workgroups are resident (they announce
-// themselves), so the heads are never queued behind thousands of tile workgroups.  (Giving the
-// heads their CUs to themselves -- a 148 KB LDS claim that leaves tiles no room -- was measured
-// too: 7 % slower; what slows a head beside the sweep is not its own CU's memory queue.)
 template <int NT>
 __global__ __launch_bounds__(NT) void k_ov2_heads(const OvBuffers B, int ld, int R, int C, int Rp,
                                                   int K, int G, int lp) {
-    if (threadIdx.x == 0)
-        __hip_atomic_fetch_add(B.bar + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     ov_heads_rich<NT>(B, ld, R, C, Rp, K, G, lp, false);
-}
-
-__global__ __launch_bounds__(64) void k_ov2_gate(const unsigned* started, unsigned target) {
-    if (threadIdx.x != 0) return;
-    unsigned spins = 0;
-    while (__hip_atomic_load(started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-        __builtin_amdgcn_s_sleep(8);
-        if (++spins > kOvSpinMax) break;  // never hold the sweep back for good
-    }
 }
 
 template <int TR>
@@ -1055,7 +1040,6 @@ struct lpr_overlap_ctx {
     hipStream_t hstream = nullptr;  // the heads' stream of the two-stream variant
     hipEvent_t ev_h[2] = {nullptr, nullptr}, ev_s[2] = {nullptr, nullptr};
     int ev_idx = 0;
-    unsigned steps = 0;          // two-stream steps launched since ov2_begin
 };
 
 namespace lpr {
@@ -1231,7 +1215,6 @@ int ov2_begin(lpr_tableau* t) {
     }
     // everything queued on the engine stream so far (prologue, control block) precedes step 0
     c->ev_idx = 0;
-    c->steps = 0;
     LPR_HIP(hipEventRecord(c->ev_s[1], t->eng->stream));
     LPR_HIP(hipEventRecord(c->ev_h[1], c->hstream));
     return LPR_OK_OPTIMAL;
@@ -1247,8 +1230,6 @@ int ov2_launch_step(lpr_tableau* t, int K, int tr, int lp) {
     hipLaunchKernelGGL((k_ov2_heads<kOvNT>), dim3(G), dim3(kOvNT), 0, H, c->b, t->ld, t->rows,
                        t->cols, c->Rp, K, G, lp);
     LPR_HIP(hipEventRecord(c->ev_h[cur], H));
-    c->steps += 1;
-    hipLaunchKernelGGL(k_ov2_gate, dim3(1), dim3(64), 0, S, c->b.bar + 2, c->steps * (unsigned)G);
     const int nct = (t->ld / 2 + kOvNT - 1) / kOvNT;
     const int nrt = (t->rows + kOvTileRows - 1) / kOvTileRows;
     if (tr >= 16)
