@@ -456,10 +456,8 @@ static int solve_overlapped(lpr_tableau* t, const lpr_solve_opts& o, int K, int 
     const int64_t max_iter = o.max_pivots > 0 ? start_iter + o.max_pivots : 0;
     rc = ov_begin(t, start_iter, max_iter);
     if (rc != LPR_OK_OPTIMAL) return rc;
-    if (two_streams) {
-        rc = ov2_begin(t);
-        if (rc != LPR_OK_OPTIMAL) return rc;
-    }
+    if (two_streams && ov2_begin(t) != LPR_OK_OPTIMAL)
+        two_streams = false;  // no second stream: the one-launch form of the overlap does the same
 
     int32_t status = kRunning, cur = 0, error = 0;
     int64_t applied = start_iter;
