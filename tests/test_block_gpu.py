@@ -196,3 +196,27 @@ def test_north_star_size_blocked_equals_one_pivot_path(engine, oracle):
     assert ha == hb
     a.destroy()
     b.destroy()
+
+
+def test_north_star_full_solve_default_equals_one_pivot_path(engine):
+    """m=4096, n=8192 solved to optimality (about 122 000 pivots) twice: the default path (16 pivots
+    per sweep, heads beside the sweep on a second stream) and one pivot per sweep.  Same status,
+    pivot count, pivot log, basis, objective bits and tableau hash."""
+    from lpr_381_group_v22_amd import Tableau
+    m, n, seed = 4096, 8192, 0
+    a = Tableau.synthetic(engine, m, n, seed)
+    ra = a.solve()
+    b = Tableau.synthetic(engine, m, n, seed)
+    rb = b.solve(block=1)
+    assert ra.block == 16 and rb.block == 1
+    assert ra.status == rb.status == 0
+    assert ra.pivots == rb.pivots > 100000
+    assert ra.z == rb.z
+    la, lb = a.pivot_log(cap=ra.pivots + 8), b.pivot_log(cap=rb.pivots + 8)
+    assert la.shape == lb.shape and (la == lb).all()
+    assert a.basis().tolist() == b.basis().tolist()
+    ha = hashlib.sha256(a.read().tobytes()).hexdigest()
+    hb = hashlib.sha256(b.read().tobytes()).hexdigest()
+    assert ha == hb
+    a.destroy()
+    b.destroy()
