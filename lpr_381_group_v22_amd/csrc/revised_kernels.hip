@@ -17,6 +17,7 @@
 //   k_rev_gemm     MultiplyMatrices(BInverse, A) (:360) on fp64 MFMA (mfma_f64_16x16x4)
 #include "engine_common.hpp"
 #include "revised_common.hpp"
+#include "fold_common.hpp"
 
 #pragma clang fp contract(off)
 
@@ -268,46 +269,20 @@ __global__ __launch_bounds__(1024) void k_rev_enter(const double* __restrict__ r
     }
 
     const int N = n + m;
-    // Candidate values are read ONCE into registers (first kCacheE * 1024 indices; anything beyond
-    // is re-read from memory): -inf marks "not a candidate" (basic, or rc <= EPS).
-    constexpr int kCacheE = 16;
-    double val[kCacheE];
-#pragma unroll
-    for (int u = 0; u < kCacheE; ++u) {
-        const int k = tid + u * nt;
-        double rc = -INFINITY;
-        if (k < N && !is_basic[k]) {
-            rc = (k < n) ? rcx[k] : -y[k - n];  // rcS_k = -y_k (:100-102)
-            if (!(rc > kEps)) rc = -INFINITY;
-        }
-        val[u] = rc;
-    }
-    int cur = -1;             // enteringIdx
-    double best = -INFINITY;  // bestPosRC
-    for (;;) {
-        int first = INT_MAX;
-#pragma unroll
-        for (int u = 0; u < kCacheE; ++u) {
-            const int k = tid + u * nt;
-            if (first == INT_MAX && k > cur && val[u] > -INFINITY &&
-                (cur == -1 || val[u] > best + kEps))
-                first = k;  // this lane's indices ascend: its first hit is its smallest
-        }
-        if (first == INT_MAX) {
-            for (int k = tid + kCacheE * nt; k < N; k += nt) {
-                if (k <= cur || is_basic[k]) continue;
-                const double rc = (k < n) ? rcx[k] : -y[k - n];
-                if (rc > kEps && (cur == -1 || rc > best + kEps)) {
-                    first = k;
-                    break;
-                }
-            }
-        }
-        first = block_min_int(first, lds);
-        if (first == INT_MAX) break;
-        cur = first;
-        best = (cur < n) ? rcx[cur] : -y[cur - n];
-    }
+    // "rc > EPS, and first or rc > best + EPS" over ascending non-basic indices (:105-121; the
+    // equal-within-EPS clause needs a smaller index than the current one and can never fire in
+    // ascending order).  With v = -rc this is eps_fold's "v < best - EPS" from best = +inf:
+    // negation is exact, and fl(-b - EPS) = -fl(b + EPS).
+    __shared__ int lds_i2[32];
+    __shared__ double lds_v2[32];
+    const int cur = eps_fold<16>(
+        0, N, INFINITY,
+        [&](int k) {
+            if (is_basic[k]) return (double)NAN;
+            const double rc = (k < n) ? rcx[k] : -y[k - n];  // rcS_k = -y_k (:100-102)
+            return (rc > kEps) ? -rc : (double)NAN;
+        },
+        lds_i2, lds_v2);
     if (tid == 0) {
         st->entering = cur;
         if (cur < 0) st->status = LPR_OK_OPTIMAL;  // :124-146
@@ -351,6 +326,7 @@ __global__ __launch_bounds__(1024) void k_rev_ratio(const double* __restrict__ u
                                                     int32_t* __restrict__ log, int n, int m,
                                                     RevState* st) {
     __shared__ int lds[16];
+    __shared__ double lds_best;
     if (st->status != kRunning) return;
     const int tid = threadIdx.x;
     const int nt = blockDim.x;
@@ -401,11 +377,21 @@ __global__ __launch_bounds__(1024) void k_rev_ratio(const double* __restrict__ u
                 }
             }
         }
+        const int mine = first;
         first = block_min_int(first, lds);
         if (first == INT_MAX) break;
+        if (mine == first) {  // exactly one lane found it: publish its ratio
+            double v = NAN;
+#pragma unroll
+            for (int q = 0; q < kCacheR; ++q)
+                if (tid + q * nt == first) v = rat[q];
+            if (first >= kCacheR * nt) v = xB[first] / u[first];
+            lds_best = v;
+        }
+        __syncthreads();
         cur = first;
         row = first;
-        best = xB[first] / u[first];
+        best = lds_best;
     }
     if (row < 0) {
         if (tid == 0) st->status = LPR_UNBOUNDED;  // :178-179
