@@ -193,6 +193,14 @@ def run_primal(args, D: Dist):
                     "element once for all its pivots; hbm_side_frac is the physical traffic "
                     "(PMC) / launch time / peak.  A step lasts as long as its loop heads "
                     "(latency-bound, O(R+C) data per pivot), not as long as its sweep.")
+        if roof is None:
+            # no sweep launch of the timed region was bracketed by events (too few steps, or
+            # --no-kernel-timing): the whole-job form of the same figure, SURVEY 8(d)
+            whole = bytes_per_pivot * value / D.world / 1e9
+            roof = {"bound": "hbm", "kernel": "whole job (no per-launch timing in this run)",
+                    "achieved": round(whole, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": round(whole / HBM_PEAK_GBPS, 4), "pivots_per_launch": block,
+                    "traffic": None}
         cpu = None
         if D.world == 1 and args.cpu_pivots != 0:
             cp = args.cpu_pivots
