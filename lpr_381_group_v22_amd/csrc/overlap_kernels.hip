@@ -61,6 +61,8 @@ struct OvBuffers {      // everything the step kernel touches, passed by value
     double* bvec;       // [2][Rp] RHS column after `staged` pivots in bvec[staged & 1]
     ZPart* zparts;      // [2][kOvGroups]
     double* rparts;     // [3][kOvGroups] ratio-test partials: ratio, pivot element, row (as double); + f0
+    unsigned long long* gran;  // [3][kOvGroups][3] partials as {epoch, 32-bit value} granules:
+                               // Z-row partials bank 0 / 1, ratio partials (ov_heads_rich)
     OvCtl* ctl;         // [2]
     unsigned* bar;      // [2]
     int32_t* basis;
@@ -72,7 +74,9 @@ struct OvBuffers {      // everything the step kernel touches, passed by value
 __global__ __launch_bounds__(1024) void k_ov_prologue(const double* __restrict__ T, int ld, int R,
                                                       int C, double* __restrict__ zrow,
                                                       double* __restrict__ bvec0,
-                                                      ZPart* __restrict__ bank, int G) {
+                                                      ZPart* __restrict__ bank, int G,
+                                                      unsigned long long* __restrict__ gbank,
+                                                      unsigned epoch) {
     __shared__ double lds_v[16];
     __shared__ int lds_i[16];
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -89,8 +93,15 @@ __global__ __launch_bounds__(1024) void k_ov_prologue(const double* __restrict__
     }
     c = block_cand_min(c, lds_v, lds_i);
     if (tid < G) {
-        bank[tid].v = (tid == 0) ? c.v : 0.0;
-        bank[tid].i = (tid == 0) ? c.i : -1;
+        const double v = (tid == 0) ? c.v : 0.0;
+        const int i = (tid == 0) ? c.i : -1;
+        bank[tid].v = v;
+        bank[tid].i = i;
+        // the same partials as granules (ov_heads_rich), see gr_publish
+        const unsigned long long e = (unsigned long long)epoch << 32;
+        gbank[tid * 3 + 0] = e | (unsigned)__double2loint(v);
+        gbank[tid * 3 + 1] = e | (unsigned)__double2hiint(v);
+        gbank[tid * 3 + 2] = e | (unsigned)i;
     }
     for (int i = tid; i < R; i += nt) bvec0[i] = T[(size_t)i * ld + (C - 1)];
 }
@@ -473,6 +484,52 @@ __device__ void ov_heads(const OvBuffers B, int ld, int R, int C, int Rp, int K,
     }
 }
 
+// ---- partials as granules (the data is the flag) ------------------------------------------------
+// A partial (double v, int i) of workgroup g is three 8-byte granules {epoch << 32 | 32 bits}, each
+// written by one sc1 store; a reader re-reads them until all three carry the epoch it waits for.
+// That is the barrier and the data transfer in one memory round trip: a workgroup publishes its
+// partial after its other stores have drained (s_waitcnt + workgroup barrier), so a reader that
+// holds all G partials of an epoch also knows that every workgroup's stores of that phase landed.
+__device__ __forceinline__ void gr_publish(unsigned long long* g3, unsigned epoch, double v, int i) {
+    const unsigned long long e = (unsigned long long)epoch << 32;
+    __hip_atomic_store(g3 + 0, e | (unsigned)__double2loint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(g3 + 1, e | (unsigned)__double2hiint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(g3 + 2, e | (unsigned)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One wave: lane l < G fetches workgroup l's partial of `epoch`; returns the lexicographic minimum
+// (value, then index; index < 0 = no candidate) in every lane, or sets *fail after kOvSpinMax polls.
+__device__ __forceinline__ Cand gr_collect(const unsigned long long* base, int G, unsigned epoch,
+                                           double none, int* fail) {
+    const int lane = threadIdx.x & (kWave - 1);
+    Cand c;
+    c.v = none;
+    c.i = -1;
+    for (unsigned spins = 0;; ++spins) {
+        bool ok = true;
+        if (lane < G) {
+            const unsigned long long a = __hip_atomic_load(base + lane * 3 + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long b = __hip_atomic_load(base + lane * 3 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long d = __hip_atomic_load(base + lane * 3 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = (unsigned)(a >> 32) == epoch && (unsigned)(b >> 32) == epoch &&
+                 (unsigned)(d >> 32) == epoch;
+            c.v = __hiloint2double((int)(unsigned)b, (int)(unsigned)a);
+            c.i = (int)(unsigned)d;
+        }
+        if (__all(ok)) break;
+        if (spins > kOvSpinMax) {
+            *fail = 1;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    if (lane >= G) {
+        c.v = none;
+        c.i = -1;
+    }
+    return wave_cand_min(c);
+}
+
 // ------------------------------------------------------------------------------------------
 // The heads again, for the launches where they have a kernel (and so a register file) of their
 // own (k_ov_heads, k_ov2_heads).  Same protocol and arithmetic as ov_heads; what differs is where
@@ -496,6 +553,7 @@ __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, i
     __shared__ double s_fa[kOvMax], s_fn[kOvMax];       // f_t[r] of the earlier pivots
     __shared__ double s_pa[kOvMax], s_pn[kOvMax];       // p_t[e] of the earlier pivots
     __shared__ double s_parhs[kOvMax], s_prhs[kOvMax];  // p_t[rhs]: block being swept / this block
+    __shared__ int s_pick[2];  // [0] the index a collect returned, [1] it timed out
     const int tid = threadIdx.x, nt = blockDim.x;
     const int g = blockIdx.x;
     const bool lead = (g == 0);
@@ -516,7 +574,6 @@ __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, i
     double* fcolA = B.fcol + (size_t)sa * slotF;
     double* prowN = B.prow + (size_t)(sa ^ 1) * slotP;
     double* fcolN = B.fcol + (size_t)(sa ^ 1) * slotF;
-    unsigned* bar = B.bar + lp;
     const double2* Tin2 = reinterpret_cast<const double2*>(Tin);
     const double2* prowA2 = reinterpret_cast<const double2*>(prowA);
     double2* zrow2 = reinterpret_cast<double2*>(B.zrow);
@@ -544,21 +601,32 @@ __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, i
     int32_t status_out = status;
     int count = 0;
     int err = 0;
-    unsigned nbar = 0;
 
     if (status == kRunning && pend_in != kRunning) {
         status_out = pend_in;  // the block staged before is being swept by this very launch
     } else if (status == kRunning) {
         for (int q = 1; q <= K; ++q) {
             const int64_t pidx = staged0 + q - 1;
-            const ZPart* bank_in = B.zparts + (pidx & 1) * kOvGroups;
-            ZPart* bank_out = B.zparts + ((pidx + 1) & 1) * kOvGroups;
             const double* bprev = B.bvec + (size_t)(pidx & 1) * Rp;
             double* bnew = B.bvec + (size_t)((pidx + 1) & 1) * Rp;
             double* colq = fcolN + (size_t)(q - 1) * Rp;
 
             // ---- entering column (:152-167) from the partials of the previous head ----
-            const int e = ov_reduce_zparts(bank_in, G).i;
+            if (tid < kWave) {  // wave 0 collects the G partials (this is also the barrier)
+                int fail = 0;
+                const Cand zc = gr_collect(B.gran + (size_t)(pidx & 1) * 3 * kOvGroups, G,
+                                           (unsigned)(2 * pidx + 1), 0.0, &fail);
+                if (tid == 0) {
+                    s_pick[0] = zc.i;
+                    s_pick[1] = fail;
+                }
+            }
+            __syncthreads();
+            const int e = s_pick[0];
+            if (s_pick[1]) {
+                err = 1;
+                break;
+            }
             if (e < 0) {
                 pend_out = LPR_OK_OPTIMAL;
                 break;
@@ -597,16 +665,13 @@ __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, i
             Cand rc;
             rc.v = DBL_MAX;
             rc.i = -1;
-            double a_of_best = 0.0;
             if (have_i) {
                 xst(&colq[i_first], cq);
-                if (i_first == 0) xst(&B.rparts[3 * kOvGroups], cq);  // T[0, e]
                 if (i_first >= 1 && cq > 1e-9) {
                     const double ratio = myb / cq;
                     if (ratio >= 0) {
                         rc.v = ratio;
                         rc.i = i_first;
-                        a_of_best = cq;
                     }
                 }
             }
@@ -634,53 +699,31 @@ __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, i
                     if (ratio >= 0 && ratio < rc.v) {
                         rc.v = ratio;
                         rc.i = i;
-                        a_of_best = c;
                     }
                 }
             }
-            {   // this workgroup's (ratio, row) minimum and its pivot element -> the partials
-                const int my_best = rc.i;
-                rc = block_cand_min(rc, lds_v, lds_i);
-                if (rc.i >= 0 && my_best == rc.i) lds_p[0] = a_of_best;
-                __syncthreads();
+            // this workgroup's (ratio, row) minimum -> its partial, published once its column slice
+            // has drained; then wave 0 collects the G partials: the leaving row (:169-191)
+            rc = block_cand_min(rc, lds_v, lds_i);
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();
+            if (tid == 0)
+                gr_publish(B.gran + (size_t)(2 * kOvGroups + g) * 3, (unsigned)(2 * pidx + 2), rc.v,
+                           rc.i);
+            if (tid < kWave) {
+                int fail = 0;
+                const Cand rr = gr_collect(B.gran + (size_t)2 * 3 * kOvGroups, G,
+                                           (unsigned)(2 * pidx + 2), DBL_MAX, &fail);
                 if (tid == 0) {
-                    xst(&B.rparts[g], rc.v);
-                    xst(&B.rparts[kOvGroups + g], rc.i >= 0 ? lds_p[0] : 0.0);
-                    xst(&B.rparts[2 * kOvGroups + g], (double)rc.i);
+                    s_pick[0] = rr.i;
+                    s_pick[1] = fail;
                 }
             }
-            if (!ov_barrier(bar, (++nbar) * (unsigned)G)) {
+            __syncthreads();
+            const int r = s_pick[0];
+            if (s_pick[1]) {
                 err = 1;
                 break;
-            }
-
-            // ---- the leaving row: lexicographic minimum of the G partials ----
-            double p, f0;
-            int r;
-            {
-                const int lane = tid & (kWave - 1);
-                Cand c;
-                c.v = DBL_MAX;
-                c.i = -1;
-                double a = 0.0;
-                if (lane < G) {
-                    c.v = xld(&B.rparts[lane]);
-                    a = xld(&B.rparts[kOvGroups + lane]);
-                    c.i = (int)xld(&B.rparts[2 * kOvGroups + lane]);
-                }
-                f0 = xld(&B.rparts[3 * kOvGroups]);
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) {
-                    Cand o;
-                    o.v = __shfl_xor(c.v, off, kWave);
-                    o.i = __shfl_xor(c.i, off, kWave);
-                    const double oa = __shfl_xor(a, off, kWave);
-                    const Cand m = cand_min(c, o);
-                    if (m.i != c.i || m.v != c.v) a = oa;
-                    c = m;
-                }
-                r = c.i;
-                p = a;
             }
             if (r < 0) {
                 pend_out = LPR_UNBOUNDED;
@@ -697,6 +740,8 @@ __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, i
             if (tid < kb) s_fa[tid] = fcolA[(size_t)tid * Rp + r];
             if (tid >= 32 && tid - 32 < q - 1) s_fn[tid - 32] = xld(&fcolN[(size_t)(tid - 32) * Rp + r]);
             double wr = (tid == 128) ? Tin[(size_t)r * ld + rhs] : 0.0;
+            const double p = xld(&colq[r]);   // the pivot element T[r, e] ...
+            const double f0 = xld(&colq[0]);  // ... and the Z row's factor T[0, e]
             __syncthreads();
             Cand n;
             n.v = 0.0;
@@ -837,23 +882,22 @@ __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, i
                 const double prod = colq[i] * prhs;
                 xst(&bnew[i], (i == r) ? prhs : bprev[i] - prod);
             }
-            if (tid == 0) {
-                xst(&bank_out[g].v, n.v);
-                xst(&bank_out[g].i, n.i);
-                if (lead) {
-                    co->r[q - 1] = r;
-                    B.basis[r - 1] = e;  // :142
-                    if (pidx < log_cap) {
-                        B.log[2 * pidx] = r;
-                        B.log[2 * pidx + 1] = e;
-                    }
+            if (lead && tid == 0) {
+                co->r[q - 1] = r;
+                B.basis[r - 1] = e;  // :142
+                if (pidx < log_cap) {
+                    B.log[2 * pidx] = r;
+                    B.log[2 * pidx + 1] = e;
                 }
             }
             count = q;
-            if (!ov_barrier(bar, (++nbar) * (unsigned)G)) {
-                err = 1;
-                break;
-            }
+            // this workgroup's Z-row partial, published once its row slice / RHS entries have
+            // drained; the next head (or the next launch) collects the G of them
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();
+            if (tid == 0)
+                gr_publish(B.gran + ((size_t)((pidx + 1) & 1) * kOvGroups + g) * 3,
+                           (unsigned)(2 * (pidx + 1) + 1), n.v, n.i);
         }
     }
 
@@ -1064,6 +1108,7 @@ void ov_release(lpr_tableau* t) {
     hipFree(c->b.bvec);
     hipFree(c->b.zparts);
     hipFree(c->b.rparts);
+    hipFree(c->b.gran);
     hipFree(c->b.ctl);
     hipFree(c->b.bar);
     if (c->h_ctl) hipHostFree(c->h_ctl);
@@ -1092,6 +1137,7 @@ int ov_ensure(lpr_tableau* t, bool second_buffer) {
     chk(hipMalloc(&c->b.bvec, (size_t)2 * c->Rp * D));
     chk(hipMalloc(&c->b.zparts, (size_t)2 * kOvGroups * sizeof(ZPart)));
     chk(hipMalloc(&c->b.rparts, (size_t)(3 * kOvGroups + 1) * sizeof(double)));
+    chk(hipMalloc(&c->b.gran, (size_t)9 * kOvGroups * sizeof(unsigned long long)));
     chk(hipMalloc(&c->b.ctl, 2 * sizeof(OvCtl)));
     chk(hipMalloc(&c->b.bar, 4 * sizeof(unsigned)));
     chk(hipHostMalloc(&c->h_ctl, 2 * sizeof(OvCtl)));
@@ -1138,9 +1184,11 @@ int ov_begin(lpr_tableau* t, int64_t iter, int64_t max_iter) {
     h[1] = h[0];
     LPR_HIP(hipMemcpyAsync(c->b.ctl, h, 2 * sizeof(OvCtl), hipMemcpyHostToDevice, s));
     LPR_HIP(hipMemsetAsync(c->b.bar, 0, 4 * sizeof(unsigned), s));
+    LPR_HIP(hipMemsetAsync(c->b.gran, 0, (size_t)9 * kOvGroups * sizeof(unsigned long long), s));
     hipLaunchKernelGGL(k_ov_prologue, dim3(1), dim3(1024), 0, s, t->T, t->ld, t->rows, t->cols,
                        c->b.zrow, c->b.bvec + (size_t)(iter & 1) * c->Rp,
-                       c->b.zparts + (iter & 1) * kOvGroups, ov_groups(t));
+                       c->b.zparts + (iter & 1) * kOvGroups, ov_groups(t),
+                       c->b.gran + (size_t)(iter & 1) * 3 * kOvGroups, (unsigned)(2 * iter + 1));
     LPR_HIP(hipGetLastError());
     return LPR_OK_OPTIMAL;
 }
