@@ -321,8 +321,11 @@ static int solve_fused(lpr_tableau* t, const lpr_solve_opts& o, lpr_solve_result
     return status;
 }
 
-// Large tableaux: K pivots per sweep (block_kernels.hip).  opts.block: 0 = auto, 1 = the
-// one-pivot-per-sweep path, 2..8 = that many.  opts.variant 0x7fff also forces the one-pivot path.
+// Tableaux above kFusedBytes: K pivots per sweep.  opts.block: 0 = auto (16), 1 = the
+// one-pivot-per-sweep path, 2..16 = that many (2..8 in block_kernels.hip's form, variant 0x60tr).
+// opts.variant: 0 = by size (heads-then-sweep up to kOverlapBytes, two-stream overlap above),
+// 0x30tr / 0x40tr / 0x50tr / 0x60tr force a form with tr-row sweep tiles, any other non-zero value
+// (a k_update tile variant, 0x7fff) the one-pivot path.
 static constexpr int kDefaultBlock = 16;
 static constexpr size_t kOverlapBytes = (size_t)300 << 20;
 
