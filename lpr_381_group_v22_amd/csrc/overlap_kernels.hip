@@ -984,6 +984,55 @@ __device__ void ov_tiles(const OvBuffers B, int ld, int R, int Rp, int G, int lp
         p[s] = (s < K) ? prow2[(size_t)s * ld2 + c2] : make_double2(0.0, 0.0);
     }
     const int iend = min(R, (rt + 1) * kOvTileRows);
+    // The common tile: a full block of kOvMax pivots, all kOvTileRows rows present, no pivot row
+    // among them.  Nothing to test per (row, pivot) then, so the TR chains of a chunk are
+    // straight-line code the scheduler can interleave.
+    bool plain = (K == kOvMax) && (iend - rt * kOvTileRows == kOvTileRows);
+#pragma unroll
+    for (int s = 0; s < kOvMax; ++s)
+        plain = plain && !(rr[s] >= rt * kOvTileRows && rr[s] < iend);
+    if (plain) {
+        for (int i0 = rt * kOvTileRows; i0 < iend; i0 += TR) {
+            double2 x[TR];
+#pragma unroll
+            for (int k = 0; k < TR; ++k) {
+                const int i = i0 + k;
+                if (INPLACE) {
+                    x[k] = Tin2[(size_t)i * ld2 + c2];
+                } else {
+                    typedef double v2d __attribute__((ext_vector_type(2)));
+                    const v2d v = __builtin_nontemporal_load(
+                        reinterpret_cast<const v2d*>(&Tin2[(size_t)i * ld2 + c2]));
+                    x[k] = make_double2(v.x, v.y);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < kOvMax; ++s) {
+#pragma unroll
+                for (int k = 0; k < TR; ++k) {
+                    const double f = s_f[s * kOvTileRows + (i0 - rt * kOvTileRows) + k];
+                    const double px = f * p[s].x;  // product rounded ...
+                    const double py = f * p[s].y;
+                    x[k].x = x[k].x - px;          // ... then the difference (:208)
+                    x[k].y = x[k].y - py;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < TR; ++k) {
+                const int i = i0 + k;
+                if (INPLACE) {
+                    Tout2[(size_t)i * ld2 + c2] = x[k];
+                } else {
+                    typedef double v2d __attribute__((ext_vector_type(2)));
+                    v2d v;
+                    v.x = x[k].x;
+                    v.y = x[k].y;
+                    __builtin_nontemporal_store(v, reinterpret_cast<v2d*>(&Tout2[(size_t)i * ld2 + c2]));
+                }
+            }
+        }
+        return;
+    }
     for (int i0 = rt * kOvTileRows; i0 < iend; i0 += TR) {  // TR rows in flight per lane
         double2 x[TR];
 #pragma unroll
