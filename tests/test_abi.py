@@ -96,7 +96,8 @@ def test_no_fma_in_pivot_kernels():
         assert "global_load_dwordx4" in body and "global_store_dwordx4" in body, name
     # the K-pivots-per-sweep kernels: the sweeps contain no division at all, so no FMA of any kind
     for fname, pat in (("block_kernels.s", r"_ZN3lpr12k_blk_update\w+"),
-                       ("overlap_kernels.s", r"_ZN3lpr10k_ov_sweep\w+")):
+                       ("overlap_kernels.s", r"_ZN3lpr10k_ov_sweep\w+"),
+                       ("overlap_kernels.s", r"_ZN3lpr11k_ov2_sweep\w+")):
         s = open(os.path.join(csrc, "_obj", fname)).read()
         bodies = re.findall(r"^(" + pat + r"):[^\n]*\n(.*?)\.Lfunc_end", s, flags=re.S | re.M)
         assert len(bodies) >= 3, fname
