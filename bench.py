@@ -26,6 +26,8 @@ import os
 import sys
 import time
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -203,13 +205,21 @@ def run_primal(args, D: Dist):
                     "traffic": None}
         cpu = None
         if D.world == 1 and args.cpu_pivots != 0:
-            cp = args.cpu_pivots
-            if cp < 0:  # ~16*R*C bytes per pivot at roughly 4 GB/s on one core -> aim at ~15 s
-                cp = max(4, min(2000, int(15.0 / (bytes_per_pivot / 4.0e9))))
             orc = _oracle()
             T, basis = orc.gen_dense_tableau(m, n, 0)
+            cp = args.cpu_pivots
             c0 = time.perf_counter()
-            st, cpu_piv, cpu_log = orc.primal_solve(T, basis, cp)
+            if cp < 0:
+                # a bounded sample of the same LP: about 12 s of one core, sized from the first 8
+                # pivots, and no longer than what the GPU has done (so the two logs can be compared)
+                st, piv0, log0 = orc.primal_solve(T, basis, 8)
+                per = (time.perf_counter() - c0) / max(1, piv0)
+                more = max(0, min(W + K, 4000, int(12.0 / max(per, 1e-6))) - piv0) if st == 5 else 0
+                st, piv1, log1 = orc.primal_solve(T, basis, more) if more > 0 else (st, 0, log0[:0])
+                cpu_piv = piv0 + piv1
+                cpu_log = np.concatenate([log0, log1]) if piv1 else log0
+            else:
+                st, cpu_piv, cpu_log = orc.primal_solve(T, basis, cp)
             cdt = time.perf_counter() - c0
             gpu_log = tab.pivot_log(cap=cpu_piv)
             q = min(len(gpu_log), len(cpu_log))
