@@ -220,3 +220,48 @@ def test_north_star_full_solve_default_equals_one_pivot_path(engine):
     assert ha == hb
     a.destroy()
     b.destroy()
+
+
+def test_random_small_lps_random_path_block_and_limits(engine, oracle):
+    """Seeded fuzz: 60 small LPs (dense / tie-heavy, some unbounded), each solved in several legs
+    with a random path, block size, batch and pivot limit per leg; every leg must leave the oracle's
+    state (status, pivots, log, basis, tableau bytes)."""
+    from lpr_381_group_v22_amd import Tableau
+    rng = np.random.RandomState(2024)
+    paths = [SEQ, OV, OV2, INPLACE]
+    seen = set()
+    for case_no in range(60):
+        m, n = int(rng.randint(2, 40)), int(rng.randint(2, 48))
+        kind = rng.randint(0, 3)
+        if kind == 0:
+            case = lp_cases.random_dense(m, n, int(rng.randint(0, 1000)))
+        elif kind == 1:
+            case = lp_cases.tie_heavy(m, n, int(rng.randint(0, 1000)))
+        else:  # negated constraint rows: unbounded directions appear
+            obj, cons, is_max = lp_cases.random_dense(m, n, int(rng.randint(0, 1000)))
+            cons = [type(c)([-v if (k + j) % 3 == 0 else v for j, v in enumerate(c.Coefficients)],
+                            c.Relation, c.RHS) for k, c in enumerate(cons)]
+            case = (obj, cons, is_max)
+        T, basis = _build(oracle, case)
+        tab = Tableau.from_array(engine, T, basis)
+        total = 0
+        for leg in range(6):
+            limit = int(rng.choice([1, 2, 3, 5, 9, 17, 33, 0]))
+            variant = int(rng.choice(paths))
+            kmax = 8 if variant == INPLACE else 16
+            block = int(rng.randint(2, kmax + 1))
+            batch = int(rng.choice([0, 1, 3, 7, 40]))
+            st, piv, log = oracle.primal_solve(T, basis, limit if limit else 100000)
+            res = tab.solve(max_pivots=limit if limit else 100000, block=block, variant=variant,
+                            batch=batch)
+            total += piv
+            tag = (case_no, leg, hex(variant), block, limit, batch)
+            assert res.status == st and res.pivots == piv and res.total_pivots == total, tag
+            assert tab.pivot_log().tolist()[total - piv:] == log.tolist(), tag
+            assert tab.basis().tolist() == basis.tolist(), tag
+            assert tab.read().tobytes() == T.tobytes(), tag
+            seen.add(st)
+            if st != 5:
+                break
+        tab.destroy()
+    assert {0, 1, 5} <= seen
