@@ -265,3 +265,30 @@ def test_random_small_lps_random_path_block_and_limits(engine, oracle):
                 break
         tab.destroy()
     assert {0, 1, 5} <= seen
+
+
+def test_random_wide_lps_many_head_groups(engine, oracle):
+    """The same fuzz on wide LPs (1 500 - 5 000 columns, few rows): 6 - 20 head workgroups exchange
+    their partials; cheap for the oracle."""
+    from lpr_381_group_v22_amd import Tableau
+    rng = np.random.RandomState(77)
+    for case_no in range(10):
+        m, n = int(rng.randint(8, 70)), int(rng.randint(1500, 5000))
+        gen = lp_cases.random_dense if case_no % 2 == 0 else lp_cases.tie_heavy
+        T, basis = _build(oracle, gen(m, n, int(rng.randint(0, 1000))))
+        tab = Tableau.from_array(engine, T, basis)
+        total = 0
+        for leg in range(4):
+            limit = int(rng.choice([7, 16, 31, 50, 0]))
+            variant = int(rng.choice([SEQ, OV, OV2, INPLACE]))
+            block = int(rng.randint(2, (8 if variant == INPLACE else 16) + 1))
+            st, piv, log = oracle.primal_solve(T, basis, limit if limit else 100000)
+            res = tab.solve(max_pivots=limit if limit else 100000, block=block, variant=variant)
+            total += piv
+            tag = (case_no, leg, hex(variant), block, limit, m, n)
+            assert res.status == st and res.pivots == piv and res.total_pivots == total, tag
+            assert tab.pivot_log().tolist()[total - piv:] == log.tolist(), tag
+            assert tab.read().tobytes() == T.tobytes(), tag
+            if st != 5:
+                break
+        tab.destroy()
