@@ -452,8 +452,8 @@ def main() -> int:
                     help="pivots of the CPU baseline sample (-1: sized for ~15 s, 0: skip)")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="replay captured graphs instead of eager launches with HIP events")
-    ap.add_argument("--bb-vars", type=int, default=128)
-    ap.add_argument("--bb-cons", type=int, default=8)
+    ap.add_argument("--bb-vars", type=int, default=512)
+    ap.add_argument("--bb-cons", type=int, default=64)
     ap.add_argument("--bb-levels", type=int, default=9)
     args = ap.parse_args()
     D = Dist(args)
