@@ -1,15 +1,17 @@
 #!/usr/bin/env python3
 """Benchmarks of the MI355X simplex pivot engine.  Rank 0 prints ONE JSON line.
 
-    python bench.py --gpus 1 --steps 512 --warmup 64                      # headline (default)
+    python bench.py --gpus 1 --steps 64 --warmup 8                        # headline (default)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
 --workload primal (default, BASELINE.json's metric): full-tableau primal-simplex pivots/s on the
     dense random LP m=4096, n=8192 (4097 x 12289 fp64 tableau, 402.8 MB) and the HBM-roofline
-    fraction of the rank-1 update kernel.  A "step" is one pivot: k_pivot_head (entering arg-min,
-    ratio-test arg-min, pivot-row normalise) + k_update (rank-1 row elimination of the whole
-    tableau).  The tableau is generated on the device and resident in HBM before the timed region;
+    fraction of the sweep kernel.  A "step" is one pass of the hot path over the tableau: one
+    sweep, which applies 16 pivots (each element read once, taken through 16 rounded
+    multiply-subtract steps in registers, written once), beside the loop heads that decide the next
+    16 (entering arg-min, ratio-test arg-min, pivot-row normalise); --block 1 = one pivot per step.
+    The tableau is generated on the device and resident in HBM before the timed region;
     nothing crosses PCIe inside it.  With N > 1 every rank owns one GPU and solves its own LP
     replica (seed = rank): the path shards by independent sub-problems, no data-path collective.
 --workload revised (BASELINE configs[2]): revised-simplex iterations/s at the same size and the
@@ -65,7 +67,8 @@ def _pmc_traffic(m: int, n: int, block: int = 1) -> dict:
             with open(path) as f:
                 d = json.load(f)
             t = d.get("k_update_traffic_per_launch", {})
-            if t.get("algorithmic_bytes") == block * 2 * 8 * (m + 1) * (n + m + 1) and \
+            if t.get("algorithmic_bytes") in (block * 2 * 8 * (m + 1) * (n + m + 1),
+                                              2 * 8 * (m + 1) * (n + m + 1)) and \
                     int(t.get("pivots_per_launch", 1)) == block:
                 best = {"traffic": int(t["hbm_side_bytes"]),
                         "traffic_source": os.path.relpath(path, ROOT)}
@@ -125,7 +128,16 @@ class Dist:
 
 
 # ------------------------------------------------------------------------------------ primal
+def _sha(a) -> str:
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
 def run_primal(args, D: Dist):
+    """A step is one pass of the hot path over the whole tableau: one sweep, which applies
+    `pivots_per_step` pivots (16 on the large-tableau paths, 1 with --block 1 and on the small
+    paths) together with the loop heads that decide the next ones.  --steps K times exactly K of
+    them in ONE lpr_primal_solve call (max_pivots = K x pivots_per_step); value = pivots/s."""
     import lpr_381_group_v22_amd as pkg
     m, n, K, W = args.m, args.n, args.steps, args.warmup
     R, C = m + 1, n + m + 1
@@ -133,76 +145,68 @@ def run_primal(args, D: Dist):
     eng = pkg.Engine(D.local_rank)
     tab = pkg.Tableau.synthetic(eng, m, n, D.rank)  # one LP replica per rank (seed = rank)
     timed = not args.no_kernel_timing
+    # one pivot to learn how many pivots a step of the path chosen for this tableau applies
+    probe = tab.solve(max_pivots=1, variant=args.variant, block=args.block)
+    B = max(1, probe.block)
     if W > 0:
-        res = tab.solve(max_pivots=W, time_kernels=False, variant=args.variant, block=args.block)
-        if res.pivots != W:
+        res = tab.solve(max_pivots=W * B, time_kernels=False, variant=args.variant,
+                        block=args.block)
+        if res.pivots != W * B:
             raise SystemExit(f"warm-up ended after {res.pivots} pivots (status {res.status})")
-    k0 = tab.kernel_stats()
+    k0, s0 = tab.kernel_stats(), tab.step_stats()
     D.barrier(eng)
     t0 = time.perf_counter()
-    res = tab.solve(max_pivots=K, time_kernels=timed, variant=args.variant, block=args.block)
-    block = max(1, res.block)  # pivots applied per sweep of the tableau
+    res = tab.solve(max_pivots=K * B, time_kernels=timed, variant=args.variant, block=args.block)
     D.barrier(eng)
     dt = time.perf_counter() - t0
-    if res.pivots != K:
-        raise SystemExit(f"timed region ended after {res.pivots} of {K} pivots "
+    if res.pivots != K * B or res.block != B:
+        raise SystemExit(f"timed region ended after {res.pivots} of {K * B} pivots "
                          f"(status {res.status}); pick another seed / fewer steps")
-    k1 = tab.kernel_stats()
+    k1, s1 = tab.kernel_stats(), tab.step_stats()
     dt_max = D.max(dt)
     launches = k1[0] - k0[0]
     kern_ms = (k1[1] - k0[1]) / launches if launches else None
+    nsteps = s1[0] - s0[0]
+    step_ms = (s1[1] - s0[1]) / nsteps if nsteps else None
 
     out = None
     if D.rank == 0:
-        value = D.world * K / dt_max
-        roof = None
+        value = D.world * K * B / dt_max
+        two_stream = B > 1 and (args.variant & 0xff00) in (0, 0x3000) and R * C * 8 > (300 << 20)
+        if B == 1:
+            kname = "k_update (rank-1 row elimination, one pivot per launch)"
+        elif two_stream:
+            kname = (f"k_ov2_sweep (one read + one write of the tableau, {B} pivots applied in "
+                     f"registers; k_ov2_heads decides the next {B} beside it on a second stream)")
+        else:
+            kname = f"sweep of {B} pivots per launch (one read + one write of the tableau)"
+        roof = {"bound": "hbm", "kernel": kname, "achieved": None, "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s", "frac": None, "traffic": None,
+                "bytes_per_launch": bytes_per_pivot, "pivots_per_launch": B}
         if kern_ms:
-            # algorithmic bytes of one launch = SURVEY 8(d)'s 2*8*R*C per pivot x the pivots that
-            # launch applies.  With block > 1 the sweep still moves each element once, so the
-            # algorithmic rate can exceed the HBM peak; `traffic` is what physically moved.
-            achieved = block * bytes_per_pivot / (kern_ms * 1e-3) / 1e9
-            if block == 1:
-                kname = "k_update (rank-1 row elimination)"
-            elif (args.variant & 0xff00) in (0x4000, 0x6000):
-                kname = (f"sweep of {block} pivots (each element read once, taken through "
-                         f"{block} rounded multiply-subtract steps in registers, written once)")
-            else:
-                kname = (f"k_ov2_sweep: sweep of {block} pivots (each element read once, taken "
-                         f"through {block} rounded multiply-subtract steps in registers, written "
-                         f"once), timed together with k_ov2_heads, the loop heads of the next "
-                         f"{block} pivots, which runs concurrently on a second stream")
-            roof = {"bound": "hbm", "kernel": kname,
-                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                    "pivots_per_launch": block,
-                    "bytes_per_launch": block * bytes_per_pivot,
-                    "avg_launch_ms": round(kern_ms, 6), "launches": launches,
-                    "event_sampling": "every 4th sweep launch of the timed region",
-                    "traffic": None}
-            # SURVEY 8(d)'s whole-job form of the same figure: bytes/pivot x pivots/s
-            whole = bytes_per_pivot * value / D.world / 1e9
-            roof["achieved_whole_job"] = round(whole, 1)
-            roof["frac_whole_job"] = round(whole / HBM_PEAK_GBPS, 4)
-            roof["frac_vs_measured_copy_6290"] = round(achieved / 6290.0, 4)
-            roof.update(_pmc_traffic(m, n, block))
-            if roof.get("traffic"):
-                roof["hbm_side_frac"] = round(roof["traffic"] / (kern_ms * 1e-3) / 1e9
-                                              / HBM_PEAK_GBPS, 4)
-            if block > 1:
-                roof["note"] = (
-                    "achieved/frac follow the contract (algorithmic bytes of the pivots one launch "
-                    "applies / launch time) and exceed the HBM peak because the sweep moves each "
-                    "element once for all its pivots; hbm_side_frac is the physical traffic "
-                    "(PMC) / launch time / peak.  A step lasts as long as its loop heads "
-                    "(latency-bound, O(R+C) data per pivot), not as long as its sweep.")
-        if roof is None:
-            # no sweep launch of the timed region was bracketed by events (too few steps, or
-            # --no-kernel-timing): the whole-job form of the same figure, SURVEY 8(d)
-            whole = bytes_per_pivot * value / D.world / 1e9
-            roof = {"bound": "hbm", "kernel": "whole job (no per-launch timing in this run)",
-                    "achieved": round(whole, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": round(whole / HBM_PEAK_GBPS, 4), "pivots_per_launch": block,
-                    "traffic": None}
+            # PHYSICAL bytes of one launch (2*8*R*C: each element read once and written once,
+            # however many pivots the launch applies) / its duration by HIP events on its stream
+            achieved = bytes_per_pivot / (kern_ms * 1e-3) / 1e9
+            roof.update({"achieved": round(achieved, 1),
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                         "frac_vs_measured_copy_6290": round(achieved / 6290.0, 4),
+                         "avg_launch_ms": round(kern_ms, 6), "launches": launches,
+                         "event_sampling": ("every sweep launch of the timed region that applied "
+                                            "a full block" if B > 1 else
+                                            "every 4th update launch of the timed region")})
+        else:
+            roof["note_timing"] = "no launch of the timed region was bracketed by events"
+        if step_ms:
+            roof["avg_step_ms"] = round(step_ms, 6)
+            roof["steps_timed"] = nsteps
+        roof.update(_pmc_traffic(m, n, B))
+        if roof.get("traffic") and (step_ms or kern_ms):
+            # what the chip's memory side sustains over a whole step (sweep + heads beside it)
+            roof["hbm_side_frac"] = round(roof["traffic"] / ((step_ms or kern_ms) * 1e-3) / 1e9
+                                          / HBM_PEAK_GBPS, 4)
+        # SURVEY 8(d)'s per-pivot figure x pivots/s: what one-pivot-per-sweep would have to move
+        # to reach this pivot rate -- NOT bytes that moved when a sweep applies several pivots
+        roof["algorithmic_equivalent_gbps"] = round(bytes_per_pivot * value / D.world / 1e9, 1)
         cpu = None
         if D.world == 1 and args.cpu_pivots != 0:
             orc = _oracle()
@@ -211,37 +215,51 @@ def run_primal(args, D: Dist):
             c0 = time.perf_counter()
             if cp < 0:
                 # a bounded sample of the same LP: about 12 s of one core, sized from the first 8
-                # pivots, and no longer than what the GPU has done (so the two logs can be compared)
                 st, piv0, log0 = orc.primal_solve(T, basis, 8)
                 per = (time.perf_counter() - c0) / max(1, piv0)
-                more = max(0, min(W + K, 4000, int(12.0 / max(per, 1e-6))) - piv0) if st == 5 else 0
+                more = max(0, min(4000, int(12.0 / max(per, 1e-6))) - piv0) if st == 5 else 0
                 st, piv1, log1 = orc.primal_solve(T, basis, more) if more > 0 else (st, 0, log0[:0])
                 cpu_piv = piv0 + piv1
                 cpu_log = np.concatenate([log0, log1]) if piv1 else log0
             else:
                 st, cpu_piv, cpu_log = orc.primal_solve(T, basis, cp)
             cdt = time.perf_counter() - c0
-            gpu_log = tab.pivot_log(cap=cpu_piv)
-            q = min(len(gpu_log), len(cpu_log))
+            # the same number of pivots on a fresh device tableau (default path), then everything
+            # the two sides hold is compared: pivot log, basis, the whole tableau
+            chk = pkg.Tableau.synthetic(eng, m, n, 0)
+            cres = chk.solve(max_pivots=cpu_piv, variant=args.variant, block=args.block)
+            gpu_log = chk.pivot_log(cap=cpu_piv + 8)
+            same_log = gpu_log.shape == cpu_log.shape and bool((gpu_log == cpu_log).all())
+            same_basis = chk.basis().tolist() == basis.tolist()
+            same_tab = _sha(chk.read()) == _sha(T)
+            chk.destroy()
             cpu = {"value": round(cpu_piv / cdt, 3), "unit": "pivots/s", "cores": 1,
                    "kind": "port",
                    "sample": f"first {cpu_piv} pivots of the same LP (m={m}, n={n}, seed 0) by "
                              f"the C oracle of PrimalSimplexSolver.cs:152-211, 1 thread, "
                              f"snapshots off; cpu: {_cpu_model()}, {os.cpu_count()} logical",
-                   "pivot_log_matches_gpu": bool((gpu_log[:q] == cpu_log[:q]).all())}
+                   "gpu_status_after_same_pivots": cres.status,
+                   "pivot_log_matches_gpu": same_log, "basis_matches_gpu": same_basis,
+                   "tableau_sha256_matches_gpu": same_tab}
+        headline = (m == 4096 and n == 8192)
         out = {
-            "metric": "simplex pivots/sec on 4096x8192 fp64 tableau; % HBM roofline",
+            "metric": ("simplex pivots/sec on 4096x8192 fp64 tableau; % HBM roofline" if headline
+                       else f"simplex pivots/sec on {m}x{n} fp64 LP ({R}x{C} tableau); % HBM "
+                            f"roofline"),
             "value": round(value, 2), "unit": "pivots/s", "n_gpus": D.world, "steps": K,
             "warmup": W, "ms_per_step": round(dt_max * 1e3 / K, 6), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "pivots_per_step": B,
             "config": {"workload": f"dense random LP m={m} n={n} fp64, full-tableau primal "
                                    f"simplex pivots on the {R}x{C} tableau "
-                                   f"({R * C * 8 / 1e6:.1f} MB), one LP replica per GPU",
+                                   f"({R * C * 8 / 1e6:.1f} MB), one LP replica per GPU; a step = "
+                                   f"one sweep of the tableau = {B} pivots",
                        "m": m, "n": n, "rows": R, "cols": C, "seed": "rank",
                        "parallelism": f"replica{D.world}", "update_variant": args.variant,
-                       "pivots_per_sweep": block,
+                       "pivots_per_sweep": B, "timed_region": "one lpr_primal_solve call, "
+                       f"max_pivots = steps x {B} (pipeline fill and drain included)",
                        "launch": ("eager+events" if timed else
-                                  ("hipGraph" if block == 1 else "eager"))},
+                                  ("hipGraph" if B == 1 else "eager"))},
             "roofline": roof, "cpu_baseline": cpu,
         }
     tab.destroy()
@@ -440,8 +458,8 @@ def run_sens(args, D: Dist):
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=512)
-    ap.add_argument("--warmup", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", choices=["primal", "revised", "bb", "sens"], default="primal")
     ap.add_argument("--m", type=int, default=4096)
     ap.add_argument("--n", type=int, default=8192)
@@ -456,6 +474,10 @@ def main() -> int:
     ap.add_argument("--bb-cons", type=int, default=64)
     ap.add_argument("--bb-levels", type=int, default=9)
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 64 if args.workload == "primal" else 512
+    if args.warmup is None:
+        args.warmup = 8 if args.workload == "primal" else 64
     D = Dist(args)
     out = {"primal": run_primal, "revised": run_revised, "bb": run_bb,
            "sens": run_sens}[args.workload](args, D)

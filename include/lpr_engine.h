@@ -110,11 +110,18 @@ int lpr_tableau_shape(const lpr_tableau* t, int* rows, int* cols, int* ld);
 /* Solver options.  Zero-initialise, then set fields; defaults equal the reference's literals. */
 typedef struct lpr_solve_opts {
     int64_t max_pivots;    /* <= 0: uncapped like PrimalSimplexSolver.cs:107 */
-    int32_t time_kernels;  /* != 0: launch eagerly and bracket one rank-1 update launch in four with
-                              HIP events on the engine stream; read back with
-                              lpr_tableau_kernel_stats */
+    int32_t time_kernels;  /* != 0: launch eagerly and bracket rank-1 update / sweep launches with
+                              HIP events on the engine stream (every sweep on the K-pivot paths,
+                              one update in four on the one-pivot path); read back with
+                              lpr_tableau_kernel_stats / lpr_tableau_step_stats */
     int32_t batch;         /* pivots queued between host polls of the device status word (0: auto) */
-    int32_t variant;       /* rank-1 update kernel variant (0: auto); for tuning only, same bits */
+    int32_t variant;       /* kernel variant (0: auto); for tuning and tests only, same bits.  Low 16
+                              bits: path + sweep tile (0x30tr two-stream overlap, 0x40tr heads then
+                              in-place sweep, 0x50tr one-launch overlap, 0x60tr one launch per head;
+                              tr = 0x04/0x08/0x10 rows per chunk, 0x24/0x28 two chunks in flight).
+                              Bits 16..18, K-pivot paths: 0x10000 diagnostic time stamps of the loop
+                              heads, 0x20000 loop heads not confined to one XCD, 0x40000 confined
+                              but hand-offs through the memory side. */
     int32_t block;         /* pivots decided ahead and applied per sweep of the tableau on large
                               tableaux: 0 auto (16), 1 one pivot per sweep, 2..16 that many.  The bits
                               stored are the same for every value (each element goes through the
@@ -161,6 +168,13 @@ int lpr_pivot_log_read(lpr_tableau* t, int32_t* rows_out, int32_t* cols_out, int
 /* Timing of the rank-1 update launches recorded while opts.time_kernels was set:
  * launches, summed and average duration in milliseconds (HIP events on the engine stream). */
 int lpr_tableau_kernel_stats(lpr_tableau* t, int64_t* launches, double* total_ms, double* avg_ms);
+/* K-pivot paths: the steps timed with the sweeps above.  A step is one sweep of K pivots together
+ * with the loop heads of the next K (start of one sweep to the start of the next). */
+int lpr_tableau_step_stats(lpr_tableau* t, int64_t* steps, double* total_ms);
+/* Diagnostic (opts.variant bit 16): s_memrealtime stamps (10 ns ticks) the lead loop-head workgroup
+ * left per pivot and phase -- 64 pivots x 12 stamps, then its XCC id and whether the launch handed
+ * off through the XCD's L2.  Not part of the solver surface of the reference. */
+int lpr_debug_head_stamps(lpr_tableau* t, uint64_t* out, int64_t cap, int64_t* count);
 
 /* ------------------------------------- cutting-plane side path ("next" row f3)
  * The reference's dual simplex / second primal simplex / Gomory step (dead code in its menu,

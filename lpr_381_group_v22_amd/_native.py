@@ -127,6 +127,8 @@ SIGNATURES = {
     "lpr_basis_read": (C.c_int, [_P, _I32]),
     "lpr_pivot_log_read": (C.c_int, [_P, _I32, _I32, C.c_int64, _I64]),
     "lpr_tableau_kernel_stats": (C.c_int, [_P, _I64, _D, _D]),
+    "lpr_tableau_step_stats": (C.c_int, [_P, _I64, _D]),
+    "lpr_debug_head_stamps": (C.c_int, [_P, C.POINTER(C.c_uint64), C.c_int64, _I64]),
     "lpr_dual_solve": (C.c_int, [_P, C.c_int, C.c_int, C.c_int64, C.POINTER(SolveResult)]),
     "lpr_primal2_solve": (C.c_int, [_P, C.c_int, C.c_int, C.c_int64, C.POINTER(SolveResult)]),
     "lpr_cutting_plane": (C.c_int, [_P, C.c_int, C.c_int64, _I32, _I32]),

@@ -458,6 +458,13 @@ int blk_max_pivots() { return kBlkMax; }
 void blk_release(lpr_tableau* t) {
     lpr_block_ctx* c = static_cast<lpr_block_ctx*>(t->blk);
     if (!c) return;
+    if (t->graph) {  // a captured batch of this path holds the scratch pointers freed below
+        hipGraphExecDestroy(t->graph);
+        t->graph = nullptr;
+        t->graph_batch = 0;
+        t->graph_variant = -1;
+        t->graph_key = lpr_tableau::GraphKey();
+    }
     hipFree(c->prow);
     hipFree(c->fcol);
     hipFree(c->zrow);

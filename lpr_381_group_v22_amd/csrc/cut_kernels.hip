@@ -458,11 +458,12 @@ int cut_grow_rows(lpr_tableau* t, int rows_needed) {
     t->next_col = nc;
     t->next_rhs = nr;
     t->basis = nb;
-    if (t->graph) {
+    if (t->graph) {  // (a stale graph would also be rejected by its key: rows / T changed)
         hipGraphExecDestroy(t->graph);
         t->graph = nullptr;
         t->graph_batch = 0;
         t->graph_variant = -1;
+        t->graph_key = lpr_tableau::GraphKey();
     }
     c->row_cap = cap;
     return LPR_OK_OPTIMAL;

@@ -98,12 +98,27 @@ struct lpr_tableau {
     std::vector<hipEvent_t> ev;      // pairs (start, stop)
     int64_t timed_launches = 0;
     double timed_total_ms = 0.0;
+    int64_t timed_steps = 0;         // overlapped paths: steps (sweep || next heads) timed
+    double timed_step_ms = 0.0;
+    bool poisoned = false;           // a device-side hand-off timed out: staging state unusable
     // captured batch of (select, update) pairs
     hipGraphExec_t graph = nullptr;
     int graph_batch = 0;
     int graph_variant = -1;
-    const double* graph_T = nullptr;
+    // every kernel argument a capture bakes in: a graph is replayed only while all of them still
+    // hold (the fused / overlapped paths swap T and T2, the cut path grows rows, the log and the
+    // block scratch are re-allocated on demand)
+    struct GraphKey {
+        const void *T = nullptr, *T2 = nullptr, *log = nullptr, *basis = nullptr, *blk = nullptr;
+        const void *next_col = nullptr, *colbuf = nullptr;
+        int rows = 0, cols = 0, ld = 0;
+        bool operator==(const GraphKey& o) const {
+            return T == o.T && T2 == o.T2 && log == o.log && basis == o.basis && blk == o.blk &&
+                   next_col == o.next_col && colbuf == o.colbuf && rows == o.rows &&
+                   cols == o.cols && ld == o.ld;
+        }
+    } graph_key;
     void* ov = nullptr;               // lpr_overlap_ctx of the overlapped K-pivot path (overlap_kernels.hip)
     void* blk = nullptr;              // lpr_block_ctx of the K-pivots-per-sweep path (block_kernels.hip)
-    void* cut = nullptr;              // lpr_cut_ctx of the cutting-plane side path (cut_kernels.hip)  // T at capture time (the fused path alternates T / T2)
+    void* cut = nullptr;              // lpr_cut_ctx of the cutting-plane side path (cut_kernels.hip)
 };

@@ -52,13 +52,19 @@ int ov_ensure(lpr_tableau* t, bool second_buffer);
 int ov_begin(lpr_tableau* t, int64_t iter, int64_t max_iter);
 int ov_set_log(lpr_tableau* t, int parity);
 void ov_launch_step(lpr_tableau* t, int K, int tr, int lp);
-void ov_launch_heads(lpr_tableau* t, int K);
+void ov_launch_heads(lpr_tableau* t, int K, int flags);
 int ov2_begin(lpr_tableau* t);
-int ov2_launch_step(lpr_tableau* t, int K, int tr, int lp);
+int ov2_launch_step(lpr_tableau* t, int K, int tr, int lp, int flags, hipEvent_t ev_start,
+                    hipEvent_t ev_stop);
+int ov_read_stamps(lpr_tableau* t, uint64_t* out, int64_t cap, int64_t* count);
 int ov2_join(lpr_tableau* t);
 void ov_launch_sweep(lpr_tableau* t, int tr);
-int ov_poll(lpr_tableau* t, int parity, int32_t* status, int32_t* cur, int64_t* applied,
-            int32_t* error);
+struct OvPoll {
+    int32_t status, pending, kdone, cur, error;
+    int64_t applied;
+    double z[2];  // RHS column entry 0 (= T[0, cols-1]) after an even / odd number of pivots
+};
+int ov_poll(lpr_tableau* t, int parity, OvPoll* out);
 void ov_adopt_buffer(lpr_tableau* t, int cur);
 // revised_engine.hip
 void rev_orphan(lpr_revised* s);
@@ -72,7 +78,8 @@ void lpr_cut_release(lpr_tableau* t);
 namespace lpr {
 
 enum : int { kSelEnter = 1, kSelLeave = 2, kSelCommit = 4, kSelFull = 7 };
-constexpr int kTimeStride = 4;  // opts.time_kernels samples one update launch in four
+constexpr int kTimeStride = 4;  // opts.time_kernels samples one update launch in four (one-pivot
+                                // and 0x60tr paths; the overlapped paths time every sweep)
 
 static int alloc_tableau(lpr_engine* e, int rows, int cols, lpr_tableau** out) {
     if (!e || !out || rows < 1 || cols < 2 || rows > 65535) {
@@ -127,6 +134,34 @@ static void drop_graph(lpr_tableau* t) {
     }
     t->graph_batch = 0;
     t->graph_variant = -1;
+    t->graph_key = lpr_tableau::GraphKey();
+}
+
+// what a capture made now would bake in
+static lpr_tableau::GraphKey graph_key_now(const lpr_tableau* t) {
+    lpr_tableau::GraphKey k;
+    k.T = t->T;
+    k.T2 = t->T2;
+    k.log = t->log;
+    k.basis = t->basis;
+    k.blk = t->blk;
+    k.next_col = t->next_col;
+    k.colbuf = t->colbuf;
+    k.rows = t->rows;
+    k.cols = t->cols;
+    k.ld = t->ld;
+    return k;
+}
+
+static bool graph_valid(const lpr_tableau* t, int batch, int variant) {
+    return t->graph && t->graph_batch == batch && t->graph_variant == variant &&
+           t->graph_key == graph_key_now(t);
+}
+
+static void graph_stamp(lpr_tableau* t, int batch, int variant) {
+    t->graph_batch = batch;
+    t->graph_variant = variant;
+    t->graph_key = graph_key_now(t);
 }
 
 // Frees everything the tableau holds on the device (the engine must still be alive).
@@ -250,12 +285,10 @@ static int solve_fused(lpr_tableau* t, const lpr_solve_opts& o, lpr_solve_result
         }
         // replay a captured batch (valid for the current T / T2 orientation) -- when one exists
         // already, or when enough work is ahead to pay for capturing it (a few ms)
-        const bool have = t->graph && t->graph_batch == nb && t->graph_variant == -2 &&
-                          t->graph_T == t->T;
+        const bool have = graph_valid(t, nb, -2);
         const bool full = (nb == batch) && (have || max_iter == 0 || max_iter - iter >= 4 * batch);
         if (full) {
-            if (!t->graph || t->graph_batch != nb || t->graph_variant != -2 ||
-                t->graph_T != t->T) {
+            if (!have) {
                 drop_graph(t);
                 hipGraph_t g = nullptr;
                 LPR_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
@@ -269,9 +302,7 @@ static int solve_fused(lpr_tableau* t, const lpr_solve_opts& o, lpr_solve_result
                     set_error("hipGraphInstantiate failed: %s", hipGetErrorString(ierr));
                     return LPR_DEVICE_ERROR;
                 }
-                t->graph_batch = nb;
-                t->graph_variant = -2;
-                t->graph_T = t->T;
+                graph_stamp(t, nb, -2);
             }
             LPR_HIP(hipGraphLaunch(t->graph, s));
         } else {
@@ -389,7 +420,7 @@ static int solve_blocked(lpr_tableau* t, const lpr_solve_opts& o, int K, lpr_sol
             }
         } else {
             const int gv = -100 - K * 64 - tr;  // graph key of this path
-            if (!t->graph || t->graph_batch != nb || t->graph_variant != gv) {
+            if (!graph_valid(t, nb, gv)) {
                 drop_graph(t);
                 hipGraph_t g = nullptr;
                 LPR_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
@@ -405,8 +436,7 @@ static int solve_blocked(lpr_tableau* t, const lpr_solve_opts& o, int K, lpr_sol
                     set_error("hipGraphInstantiate failed: %s", hipGetErrorString(ierr));
                     return LPR_DEVICE_ERROR;
                 }
-                t->graph_batch = nb;
-                t->graph_variant = gv;
+                graph_stamp(t, nb, gv);
             }
             LPR_HIP(hipGraphLaunch(t->graph, s));
         }
@@ -443,17 +473,25 @@ static int solve_blocked(lpr_tableau* t, const lpr_solve_opts& o, int K, lpr_sol
     return status;
 }
 
-// Large tableaux, default: K pivots per sweep with the next block's loop heads running inside the
-// same launch as the current block's (out-of-place) sweep -- overlap_kernels.hip.
+// Large tableaux, default: K pivots per sweep with the next block's loop heads running beside the
+// current block's (out-of-place) sweep -- overlap_kernels.hip.
+//
+// A "step" is one launch pair: step j sweeps block j (K pivots) while its heads decide block j + 1.
+// A call that applies N blocks takes N + 1 steps (the first only decides, the last only sweeps);
+// the host learns the outcome from the control block the last step wrote: `status`, or -- when the
+// heads found the end (`pending`) and left nothing staged (`kdone == 0`) -- `pending` itself, so no
+// further launch is needed to publish it.
+// opts.time_kernels: HIP events on the sweep's own stream bracket EVERY sweep launch (start =
+// both kernels of the previous step done); sweep time = stop - start, step time = start of the
+// next step - start of this one.  Only steps that swept a full block are counted.
 static int solve_overlapped(lpr_tableau* t, const lpr_solve_opts& o, int K, int tr, bool overlap,
-                            bool two_streams, lpr_solve_result* res) {
+                            bool two_streams, int hflags, lpr_solve_result* res) {
     lpr_engine* e = t->eng;
     hipStream_t s = e->stream;
     int rc = ov_ensure(t, overlap);
     if (rc != LPR_OK_OPTIMAL) return rc;
     const bool timed = o.time_kernels != 0;
     int nlaunch = o.batch > 0 ? (o.batch + K - 1) / K : (default_batch(t) + K - 1) / K;
-    nlaunch = (nlaunch + 1) & ~1;  // even: every batch starts on control block 0
     if (nlaunch < 2) nlaunch = 2;
     const int64_t start_iter = t->total_pivots;
     const int64_t max_iter = o.max_pivots > 0 ? start_iter + o.max_pivots : 0;
@@ -462,99 +500,106 @@ static int solve_overlapped(lpr_tableau* t, const lpr_solve_opts& o, int K, int 
     if (two_streams && ov2_begin(t) != LPR_OK_OPTIMAL)
         two_streams = false;  // no second stream: the one-launch form of the overlap does the same
 
-    int32_t status = kRunning, cur = 0, error = 0;
+    OvPoll pl;
+    pl.status = kRunning;
+    pl.pending = kRunning;
+    pl.applied = start_iter;
+    int32_t status = kRunning;
     int64_t applied = start_iter;
-    bool first_batch = true;
+    int64_t step = 0;            // launches (pairs) queued by this call; parity = control block
+    int64_t swept_full = 0;      // full blocks swept so far by this call (for the event windows)
     int idle_batches = 0;
     while (status == kRunning) {
         int nb = nlaunch;
-        if (max_iter > 0) {  // fill + blocks + the launch that publishes the status
-            const int64_t need = (max_iter - applied) / K + 4;
-            if (need < nb) nb = (int)((need + 1) & ~1);
+        if (pl.pending != kRunning) {
+            nb = 1;  // the end has been found: the staged tail is swept, the outcome published
+        } else if (max_iter > 0) {  // the blocks the limit allows (+ the step that only decides)
+            const int64_t left = max_iter - applied;
+            const int64_t need = (left + K - 1) / K + (step == 0 ? 1 : 0);
+            if (need < nb) nb = (int)need;
         }
+        if (nb < 1) nb = 1;
         const int64_t log_before = t->log_cap;
         const int32_t* log_ptr = t->log;
         rc = ensure_log(t, applied + (int64_t)(nb + 1) * K + 1);
         if (rc != LPR_OK_OPTIMAL) return rc;
         if (t->log_cap != log_before || t->log != log_ptr) {
-            rc = ov_set_log(t, 0);
+            rc = ov_set_log(t, overlap ? (int)(step & 1) : 0);
             if (rc != LPR_OK_OPTIMAL) return rc;
         }
         // One or two launches per K pivots: plain launches keep the device busy (measured: a
         // captured graph is no faster here, and capturing one costs milliseconds per solve call).
         if (timed) {
-            while ((int)t->ev.size() < 2 * nb) {
+            while ((int)t->ev.size() < 2 * nb + 2) {
                 hipEvent_t ev;
                 LPR_HIP(hipEventCreate(&ev));
                 t->ev.push_back(ev);
             }
         }
-        for (int k = 0; k < nb; ++k) {
-            const bool sample = timed && (k % kTimeStride) == 0;
+        for (int k = 0; k < nb; ++k, ++step) {
+            const int lp = (int)(step & 1);
             if (two_streams) {
-                if (sample) {  // the step starts when both kernels of the previous one are done
-                    rc = ov2_join(t);
-                    if (rc != LPR_OK_OPTIMAL) return rc;
-                    LPR_HIP(hipEventRecord(t->ev[2 * k], s));
-                }
-                rc = ov2_launch_step(t, K, tr, k & 1);
+                rc = ov2_launch_step(t, K, tr, lp, hflags, timed ? t->ev[2 * k] : nullptr,
+                                     timed ? t->ev[2 * k + 1] : nullptr);
                 if (rc != LPR_OK_OPTIMAL) return rc;
-                if (sample) {  // ... and ends when both of its kernels are
-                    rc = ov2_join(t);
-                    if (rc != LPR_OK_OPTIMAL) return rc;
-                    LPR_HIP(hipEventRecord(t->ev[2 * k + 1], s));
-                }
                 continue;
             }
-            if (!overlap) ov_launch_heads(t, K);
-            if (sample) LPR_HIP(hipEventRecord(t->ev[2 * k], s));
-            if (overlap) ov_launch_step(t, K, tr, k & 1);
+            if (!overlap) ov_launch_heads(t, K, hflags);
+            if (timed) LPR_HIP(hipEventRecord(t->ev[2 * k], s));
+            if (overlap) ov_launch_step(t, K, tr, lp);
             else ov_launch_sweep(t, tr);
-            if (sample) LPR_HIP(hipEventRecord(t->ev[2 * k + 1], s));
+            if (timed) LPR_HIP(hipEventRecord(t->ev[2 * k + 1], s));
         }
         if (two_streams) {
             rc = ov2_join(t);
             if (rc != LPR_OK_OPTIMAL) return rc;
         }
+        if (timed) LPR_HIP(hipEventRecord(t->ev[2 * nb], s));  // closes the last step's window
         LPR_HIP(hipGetLastError());
-        int64_t now = applied;
-        rc = ov_poll(t, 0, &status, &cur, &now, &error);
+        rc = ov_poll(t, overlap ? (int)(step & 1) : 0, &pl);
         if (rc != LPR_OK_OPTIMAL) return rc;
-        if (error || status == LPR_DEVICE_ERROR) {
-            set_error("overlapped pivot loop: a grid barrier of the loop heads timed out");
+        if (pl.error || pl.status == LPR_DEVICE_ERROR) {
+            // the staging state is unusable (a head group never arrived): the handle is poisoned
+            t->poisoned = true;
+            set_error("overlapped pivot loop: a hand-off between the loop heads timed out; the "
+                      "tableau handle is no longer usable");
             return LPR_DEVICE_ERROR;
         }
+        status = pl.status;
+        if (status == kRunning && pl.pending != kRunning && pl.kdone == 0)
+            status = pl.pending;  // the end was found and nothing is left to sweep
         if (timed) {
-            // launches sweep full blocks (K pivots) in order: first the pipeline fill (the very
-            // first launch of the call sweeps nothing), then full blocks until the solve ends
-            const int64_t swept = (now - applied) / K;
-            const int first = (first_batch && overlap) ? 1 : 0;
-            for (int k = 0; k < nb; k += kTimeStride) {
-                if (k < first || k >= first + swept) continue;
+            // steps of this batch sweep full blocks in order: first (only in the very first batch
+            // of an overlapped call) the step that sweeps nothing, then full blocks, then at most
+            // one partial block and idle steps
+            const int64_t full_now = (pl.applied - start_iter) / K - swept_full;
+            const int first = (step == nb && overlap) ? 1 : 0;
+            for (int k = first; k < nb && k < first + full_now; ++k) {
                 float ms = 0.f;
                 LPR_HIP(hipEventElapsedTime(&ms, t->ev[2 * k], t->ev[2 * k + 1]));
                 t->timed_total_ms += ms;
                 t->timed_launches += 1;
+                float st = 0.f;
+                LPR_HIP(hipEventElapsedTime(&st, t->ev[2 * k], t->ev[2 * k + 2]));
+                t->timed_step_ms += st;
+                t->timed_steps += 1;
             }
+            swept_full += full_now;
         }
-        idle_batches = (now == applied) ? idle_batches + 1 : 0;
-        applied = now;
-        first_batch = false;
+        idle_batches = (pl.applied == applied) ? idle_batches + 1 : 0;
+        applied = pl.applied;
         if (status == kRunning && idle_batches >= 3) {
             set_error("overlapped pivot loop made no progress (device status still running)");
             return LPR_DEVICE_ERROR;
         }
     }
-    ov_adopt_buffer(t, cur);
+    ov_adopt_buffer(t, pl.cur);
     t->total_pivots = applied;
     res->status = status;
     res->block = K;
     res->pivots = applied - start_iter;
     res->total_pivots = applied;
-    double z = 0.0;
-    LPR_HIP(hipMemcpyAsync(&z, t->T + (t->cols - 1), sizeof(double), hipMemcpyDeviceToHost, s));
-    LPR_HIP(hipStreamSynchronize(s));
-    res->z = z;
+    res->z = pl.z[applied & 1];  // T[0, cols-1]: the RHS column the heads carry, entry 0
     return status;
 }
 
@@ -567,6 +612,11 @@ using namespace lpr;
         if (!(t) || !(t)->eng) {                                                 \
             set_error("tableau handle is null or its engine has been closed");   \
             return LPR_BAD_ARGUMENT;                                             \
+        }                                                                        \
+        if ((t)->poisoned) {                                                     \
+            set_error("tableau handle is unusable: an earlier solve ended in a " \
+                      "device-side hand-off timeout");                           \
+            return LPR_DEVICE_ERROR;                                             \
         }                                                                        \
     } while (0)
 
@@ -794,6 +844,8 @@ int lpr_primal_solve(lpr_tableau* t, const lpr_solve_opts* opts, lpr_solve_resul
     lpr_solve_opts o;
     std::memset(&o, 0, sizeof o);
     if (opts) o = *opts;
+    const int hflags = (o.variant >> 16) & 7;  // loop-head placement / diagnostics (K-pivot paths)
+    o.variant &= 0xffff;                       // path + tile
     lpr_engine* e = t->eng;
     hipStream_t s = e->stream;
     LPR_HIP(hipSetDevice(e->device));
@@ -816,7 +868,7 @@ int lpr_primal_solve(lpr_tableau* t, const lpr_solve_opts* opts, lpr_solve_resul
             bool overlap = two_streams || (o.variant & 0xff00) == 0x5000;
             const int tr = (o.variant & 0xff00) ? (o.variant & 0xff) : 8;
             if (overlap && ov_ensure(t, true) == LPR_OUT_OF_MEMORY) overlap = false;
-            return solve_overlapped(t, o, K, tr, overlap, two_streams && overlap, res);
+            return solve_overlapped(t, o, K, tr, overlap, two_streams && overlap, hflags, res);
         }
     }
     const int variant = (o.variant > 0 && o.variant < 0x7000) ? o.variant - 1 : default_variant(t);
@@ -874,7 +926,7 @@ int lpr_primal_solve(lpr_tableau* t, const lpr_solve_opts* opts, lpr_solve_resul
             if (nb == 0 || (max_iter > 0 && iter + nb >= max_iter))
                 launch_pivot_head(t);  // closing loop head -> final status
         } else {
-            if (!t->graph || t->graph_batch != nb || t->graph_variant != variant) {
+            if (!graph_valid(t, nb, variant)) {
                 drop_graph(t);
                 hipGraph_t g = nullptr;
                 LPR_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
@@ -890,8 +942,7 @@ int lpr_primal_solve(lpr_tableau* t, const lpr_solve_opts* opts, lpr_solve_resul
                     set_error("hipGraphInstantiate failed: %s", hipGetErrorString(ierr));
                     return LPR_DEVICE_ERROR;
                 }
-                t->graph_batch = nb;
-                t->graph_variant = variant;
+                graph_stamp(t, nb, variant);
             }
             LPR_HIP(hipGraphLaunch(t->graph, s));
         }
@@ -1069,6 +1120,20 @@ int lpr_tableau_kernel_stats(lpr_tableau* t, int64_t* launches, double* total_ms
     if (total_ms) *total_ms = t->timed_total_ms;
     if (avg_ms) *avg_ms = t->timed_launches ? t->timed_total_ms / t->timed_launches : 0.0;
     return LPR_OK_OPTIMAL;
+}
+
+int lpr_tableau_step_stats(lpr_tableau* t, int64_t* steps, double* total_ms) {
+    LPR_LIVE(t);
+    if (steps) *steps = t->timed_steps;
+    if (total_ms) *total_ms = t->timed_step_ms;
+    return LPR_OK_OPTIMAL;
+}
+
+int lpr_debug_head_stamps(lpr_tableau* t, uint64_t* out, int64_t cap, int64_t* count) {
+    LPR_LIVE(t);
+    if (!count || cap < 0) return LPR_BAD_ARGUMENT;
+    LPR_HIP(hipSetDevice(t->eng->device));
+    return ov_read_stamps(t, out, cap, count);
 }
 
 }  // extern "C"

@@ -63,11 +63,17 @@ struct OvBuffers {      // everything the step kernel touches, passed by value
     double* rparts;     // [3][kOvGroups] ratio-test partials: ratio, pivot element, row (as double); + f0
     unsigned long long* gran;  // [3][kOvGroups][3] partials as {epoch, 32-bit value} granules:
                                // Z-row partials bank 0 / 1, ratio partials (ov_heads_rich)
+    unsigned long long* xgran;  // [kOvGroups] {launch epoch, XCC id} of every head workgroup
+    unsigned long long* dbg;    // diagnostic time stamps of the lead head workgroup (or null)
     OvCtl* ctl;         // [2]
     unsigned* bar;      // [2]
     int32_t* basis;
     int32_t* log;
 };
+
+constexpr int kOvStampsPerPivot = 12;   // diagnostic build of the heads (opts.variant bit 16)
+constexpr int kOvStampPivots = 64;      // pivots kept (a ring over the launches)
+constexpr size_t kOvDbgWords = (size_t)kOvStampPivots * kOvStampsPerPivot + 8;  // + xcc, mode
 
 // ------------------------------------------------------------------------------------------
 // Per solve call: Z row, RHS column and entering column of the tableau in memory.
@@ -75,11 +81,19 @@ __global__ __launch_bounds__(1024) void k_ov_prologue(const double* __restrict__
                                                       int C, double* __restrict__ zrow,
                                                       double* __restrict__ bvec0,
                                                       ZPart* __restrict__ bank, int G,
-                                                      unsigned long long* __restrict__ gbank,
-                                                      unsigned epoch) {
+                                                      unsigned long long* gbank,
+                                                      unsigned epoch,
+                                                      unsigned long long* gran_all,
+                                                      unsigned long long* __restrict__ xgran,
+                                                      unsigned* __restrict__ bar) {
     __shared__ double lds_v[16];
     __shared__ int lds_i[16];
     const int tid = threadIdx.x, nt = blockDim.x;
+    // the granule banks start from epoch 0 (the bank written below: its other workgroup slots)
+    for (int k = tid; k < 9 * kOvGroups; k += nt) gran_all[k] = 0ull;
+    for (int k = tid; k < kOvGroups; k += nt) xgran[k] = 0ull;
+    if (tid < 4) bar[tid] = 0u;
+    __syncthreads();
     Cand c;
     c.v = 0.0;
     c.i = -1;
@@ -124,6 +138,26 @@ __device__ __forceinline__ int xld(const int* p) {
 __device__ __forceinline__ void xst(int* p, int v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+
+// The same hand-off when every head workgroup of the launch sits on ONE XCD (checked per launch,
+// see ov_heads_rich): the XCD's L2 is the coherence point, so the producer stores with workgroup
+// scope (sc0: the line stays in that L2) and the consumer still loads with sc1 (past its own L1,
+// served by the L2) -- a hand-off costs an L2 round trip instead of a trip to the memory side.
+__device__ __forceinline__ void hst(double* p, double v, bool l2) {
+    if (l2) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void hst(unsigned long long* p, unsigned long long v, bool l2) {
+    if (l2) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// id (0..7) of the XCD this wave runs on
+__device__ __forceinline__ unsigned ov_xcc_id() {
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 0xfu;
+}
+__device__ __forceinline__ unsigned long long ov_now() { return __builtin_amdgcn_s_memrealtime(); }
 
 // arg-min over the G partials, one per lane (G <= 64), every wave on its own
 __device__ __forceinline__ Cand ov_reduce_zparts(const ZPart* bank, int G) {
@@ -490,11 +524,12 @@ __device__ void ov_heads(const OvBuffers B, int ld, int R, int C, int Rp, int K,
 // That is the barrier and the data transfer in one memory round trip: a workgroup publishes its
 // partial after its other stores have drained (s_waitcnt + workgroup barrier), so a reader that
 // holds all G partials of an epoch also knows that every workgroup's stores of that phase landed.
-__device__ __forceinline__ void gr_publish(unsigned long long* g3, unsigned epoch, double v, int i) {
+__device__ __forceinline__ void gr_publish(unsigned long long* g3, unsigned epoch, double v, int i,
+                                           bool l2 = false) {
     const unsigned long long e = (unsigned long long)epoch << 32;
-    __hip_atomic_store(g3 + 0, e | (unsigned)__double2loint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(g3 + 1, e | (unsigned)__double2hiint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(g3 + 2, e | (unsigned)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    hst(g3 + 0, e | (unsigned)__double2loint(v), l2);
+    hst(g3 + 1, e | (unsigned)__double2hiint(v), l2);
+    hst(g3 + 2, e | (unsigned)i, l2);
 }
 
 // One wave: lane l < G fetches workgroup l's partial of `epoch`; returns the lexicographic minimum
@@ -542,9 +577,18 @@ __device__ __forceinline__ Cand gr_collect(const unsigned long long* base, int G
 // after the barrier the ratio partials, then T[r, c] with the f_t[r] -- instead of about ten.
 // Lanes of very tall / wide tableaux own further rows / column pairs; those go through memory
 // (the loops marked "further").
-template <int NT>
+//
+// Placement: the launch has `spread` x G workgroups and only every spread-th one works (g =
+// blockIdx.x / spread).  Workgroups are dealt round-robin over the 8 XCDs, so with spread = 8 the
+// G working ones normally share an XCD -- that is not a guarantee, so every launch checks it: each
+// workgroup publishes its XCC id through the memory side, all collect the G ids, and only when
+// they are equal do the hand-offs of this launch go through that XCD's L2 (hst / gr_publish with
+// l2 = true); otherwise they take the memory-side form.  Same bits either way.
+// STAMP: diagnostic build, the lead workgroup leaves s_memrealtime stamps per phase in B.dbg.
+template <int NT, bool STAMP>
 __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, int K, int G, int lp,
-                              bool solo) {
+                              bool solo, int spread, int no_l2) {
+    if ((int)blockIdx.x % spread != 0) return;
     __shared__ double lds_v[16];
     __shared__ int lds_i[16];
     __shared__ double lds_p[2];
@@ -555,7 +599,7 @@ __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, i
     __shared__ double s_parhs[kOvMax], s_prhs[kOvMax];  // p_t[rhs]: block being swept / this block
     __shared__ int s_pick[2];  // [0] the index a collect returned, [1] it timed out
     const int tid = threadIdx.x, nt = blockDim.x;
-    const int g = blockIdx.x;
+    const int g = (int)blockIdx.x / spread;
     const bool lead = (g == 0);
     const OvCtl* ci = B.ctl + lp;
     OvCtl* co = B.ctl + (lp ^ 1);
@@ -564,6 +608,20 @@ __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, i
     const int kb = solo ? 0 : ci->kdone;
     const int sa = ci->slot;
     const int64_t staged0 = ci->staged;
+    const bool staging = (status == kRunning && pend_in == kRunning);
+    const unsigned my_xcc = ov_xcc_id();
+    const unsigned xepoch = (unsigned)(staged0 + 1);  // unique per staging launch of a solve call
+    if (staging && tid == 0)  // collected below, after the register fills have been requested
+        __hip_atomic_store(B.xgran + g, ((unsigned long long)xepoch << 32) | my_xcc,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long* stamp = nullptr;
+    if (STAMP && lead && tid == 0) stamp = B.dbg;
+#define OV_STAMP(q_, k_)                                                                       \
+    do {                                                                                       \
+        if (STAMP && stamp)                                                                    \
+            stamp[(size_t)(((staged0 + (q_)-1) % kOvStampPivots) * kOvStampsPerPivot) + (k_)] = \
+                ov_now();                                                                      \
+    } while (0)
     const int64_t mx = ci->max_iter;
     const int64_t log_cap = ci->log_cap;
     const double* __restrict__ Tin = B.Tb[ci->cur];
@@ -601,12 +659,49 @@ __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, i
     int32_t status_out = status;
     int count = 0;
     int err = 0;
+    bool l2 = false;  // hand-offs through the XCD's L2 (all G workgroups share one XCD)
 
     if (status == kRunning && pend_in != kRunning) {
         status_out = pend_in;  // the block staged before is being swept by this very launch
     } else if (status == kRunning) {
-        for (int q = 1; q <= K; ++q) {
+        {   // where did the G workgroups land?  (memory-side exchange, once per launch)
+            if (tid < kWave) {
+                unsigned xo = my_xcc;
+                bool same = true;
+                int fail = 0;
+                for (unsigned spins = 0;; ++spins) {
+                    bool ok = true;
+                    if (tid < G) {
+                        const unsigned long long v = __hip_atomic_load(
+                            B.xgran + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = (unsigned)(v >> 32) == xepoch;
+                        xo = (unsigned)v;
+                    }
+                    if (__all(ok)) break;
+                    if (spins > kOvSpinMax) {
+                        fail = 1;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                same = __all(tid >= G || xo == my_xcc);
+                if (tid == 0) {
+                    s_pick[0] = (same && !no_l2 && !fail) ? 1 : 0;
+                    s_pick[1] = fail;
+                }
+            }
+            __syncthreads();
+            l2 = s_pick[0] != 0;
+            if (s_pick[1]) err = 1;
+            __syncthreads();
+            if (STAMP && stamp) {
+                B.dbg[(size_t)kOvStampPivots * kOvStampsPerPivot + 0] = my_xcc;
+                B.dbg[(size_t)kOvStampPivots * kOvStampsPerPivot + 1] = l2 ? 1u : 0u;
+            }
+        }
+        for (int q = 1; q <= K && !err; ++q) {
             const int64_t pidx = staged0 + q - 1;
+            OV_STAMP(q, 0);
             const double* bprev = B.bvec + (size_t)(pidx & 1) * Rp;
             double* bnew = B.bvec + (size_t)((pidx + 1) & 1) * Rp;
             double* colq = fcolN + (size_t)(q - 1) * Rp;
@@ -627,6 +722,7 @@ __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, i
                 err = 1;
                 break;
             }
+            OV_STAMP(q, 1);  // entering column known
             if (e < 0) {
                 pend_out = LPR_OK_OPTIMAL;
                 break;
@@ -635,7 +731,12 @@ __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, i
             double cq = have_i ? Tin[(size_t)i_first * ld + e] : 0.0;
             if (tid < kb) s_pa[tid] = prowA[(size_t)tid * ld + e];
             if (tid >= 32 && tid - 32 < q - 1) s_pn[tid - 32] = xld(&prowN[(size_t)(tid - 32) * ld + e]);
+            if (STAMP) {
+                __builtin_amdgcn_s_waitcnt(0);
+                OV_STAMP(q, 2);  // this wave's column gather has arrived
+            }
             __syncthreads();
+            OV_STAMP(q, 3);
 #pragma unroll
             for (int t = 0; t < kOvMax; ++t) {  // through the block being swept
                 if (t < kb) {
@@ -666,10 +767,10 @@ __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, i
             rc.v = DBL_MAX;
             rc.i = -1;
             if (have_i) {
-                xst(&colq[i_first], cq);
+                hst(&colq[i_first], cq, l2);
                 if (i_first >= 1 && cq > 1e-9) {
                     const double ratio = myb / cq;
-                    if (ratio >= 0) {
+                    if (ratio >= 0 && ratio < DBL_MAX) {  // :184, minRatio starts at MaxValue
                         rc.v = ratio;
                         rc.i = i_first;
                     }
@@ -693,7 +794,7 @@ __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, i
                         c = c - prod;
                     }
                 }
-                xst(&colq[i], c);
+                hst(&colq[i], c, l2);
                 if (c > 1e-9) {
                     const double ratio = bprev[i] / c;
                     if (ratio >= 0 && ratio < rc.v) {
@@ -704,12 +805,15 @@ __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, i
             }
             // this workgroup's (ratio, row) minimum -> its partial, published once its column slice
             // has drained; then wave 0 collects the G partials: the leaving row (:169-191)
+            OV_STAMP(q, 4);
             rc = block_cand_min(rc, lds_v, lds_i);
+            OV_STAMP(q, 5);
             __builtin_amdgcn_s_waitcnt(0);
             __syncthreads();
+            OV_STAMP(q, 6);  // column slice drained
             if (tid == 0)
                 gr_publish(B.gran + (size_t)(2 * kOvGroups + g) * 3, (unsigned)(2 * pidx + 2), rc.v,
-                           rc.i);
+                           rc.i, l2);
             if (tid < kWave) {
                 int fail = 0;
                 const Cand rr = gr_collect(B.gran + (size_t)2 * 3 * kOvGroups, G,
@@ -725,6 +829,7 @@ __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, i
                 err = 1;
                 break;
             }
+            OV_STAMP(q, 7);  // leaving row known
             if (r < 0) {
                 pend_out = LPR_UNBOUNDED;
                 break;
@@ -742,6 +847,10 @@ __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, i
             double wr = (tid == 128) ? Tin[(size_t)r * ld + rhs] : 0.0;
             const double p = xld(&colq[r]);   // the pivot element T[r, e] ...
             const double f0 = xld(&colq[0]);  // ... and the Z row's factor T[0, e]
+            if (STAMP) {
+                __builtin_amdgcn_s_waitcnt(0);
+                OV_STAMP(q, 8);  // this wave's row gather has arrived
+            }
             __syncthreads();
             Cand n;
             n.v = 0.0;
@@ -782,8 +891,8 @@ __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, i
 #pragma unroll
                 for (int t = 0; t < kOvMax; ++t)
                     if (t == q - 1) myp[t] = pq;
-                xst(&prowN[(size_t)(q - 1) * ld + j], pq.x);
-                xst(&prowN[(size_t)(q - 1) * ld + j + 1], pq.y);
+                hst(&prowN[(size_t)(q - 1) * ld + j], pq.x, l2);
+                hst(&prowN[(size_t)(q - 1) * ld + j + 1], pq.y, l2);
                 const double mxp = f0 * pq.x;  // :208 product rounded, then the difference
                 const double myp2 = f0 * pq.y;
                 myz.x = myz.x - mxp;
@@ -831,8 +940,8 @@ __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, i
                 double2 pq;
                 pq.x = (j < C) ? ww.x / p : 0.0;
                 pq.y = (j + 1 < C) ? ww.y / p : 0.0;
-                xst(&prowN[(size_t)(q - 1) * ld + j], pq.x);
-                xst(&prowN[(size_t)(q - 1) * ld + j + 1], pq.y);
+                hst(&prowN[(size_t)(q - 1) * ld + j], pq.x, l2);
+                hst(&prowN[(size_t)(q - 1) * ld + j + 1], pq.y, l2);
                 const double mxp = f0 * pq.x;
                 const double myp2 = f0 * pq.y;
                 z.x = z.x - mxp;
@@ -847,6 +956,7 @@ __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, i
                     n.i = j + 1;
                 }
             }
+            OV_STAMP(q, 9);
             n = block_cand_min(n, lds_v, lds_i);
 
             // ---- RHS column after this pivot ----
@@ -876,11 +986,11 @@ __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, i
             if (have_i) {
                 const double prod = cq * prhs;
                 myb = (i_first == r) ? prhs : myb - prod;
-                xst(&bnew[i_first], myb);
+                hst(&bnew[i_first], myb, l2);
             }
             for (int i = i_first + G * nt; i < R; i += G * nt) {  // further rows of this lane
                 const double prod = colq[i] * prhs;
-                xst(&bnew[i], (i == r) ? prhs : bprev[i] - prod);
+                hst(&bnew[i], (i == r) ? prhs : bprev[i] - prod, l2);
             }
             if (lead && tid == 0) {
                 co->r[q - 1] = r;
@@ -892,14 +1002,19 @@ __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, i
             }
             count = q;
             // this workgroup's Z-row partial, published once its row slice / RHS entries have
-            // drained; the next head (or the next launch) collects the G of them
+            // drained; the next head collects the G of them.  The partial of the launch's LAST
+            // head is collected by the next launch, whose workgroups may sit on another XCD: that
+            // one always goes through the memory side.
+            OV_STAMP(q, 10);
             __builtin_amdgcn_s_waitcnt(0);
             __syncthreads();
+            OV_STAMP(q, 11);  // row slice drained
             if (tid == 0)
                 gr_publish(B.gran + ((size_t)((pidx + 1) & 1) * kOvGroups + g) * 3,
-                           (unsigned)(2 * (pidx + 1) + 1), n.v, n.i);
+                           (unsigned)(2 * (pidx + 1) + 1), n.v, n.i, l2 && q < K);
         }
     }
+#undef OV_STAMP
 
     if (lead && tid == 0) {  // the next launch's view (fields owned by the heads)
         const bool staged_now = (status == kRunning && pend_in == kRunning);
@@ -923,8 +1038,85 @@ __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, i
 // ------------------------------------------------------------------------------------------
 // The sweep of the current block (workgroups [G, ...)): every element through kdone pivots
 // (:202-210 each) in registers, buffer cur -> buffer cur ^ 1.
+//
+// A 256-lane workgroup owns a tile of kOvTileRows rows x 256 double2 columns.  A lane keeps its
+// slice of the K normalised pivot rows (p[s], 16 B each) in registers for the whole tile; the
+// factors f_s[i] are the same for every lane of the workgroup, so they come through the SCALAR
+// unit: `fcol` is a __restrict__ const kernel argument that nothing in the launch writes, the
+// index is wave-uniform, and the compiler turns the TR consecutive rows of one pivot into one
+// s_load_dwordx16 -- no LDS, no workgroup barrier, no lgkmcnt stall inside the multiply-subtract
+// chains, and the multiplies read f straight from SGPRs.
+// Rows of the tile that are pivot rows of the block (at most kOvMax of the R) would need a test per
+// (row, pivot); instead the tile runs straight-line code for every row, does not store those rows,
+// and recomputes them afterwards (normalised row p[s0], then the later pivots of the block).
+template <typename T>
+__device__ __forceinline__ T ov_ld_stream(const T* p) {  // streamed once (out-of-place sweep)
+    return __builtin_nontemporal_load(p);
+}
+
+typedef double ov_v2d __attribute__((ext_vector_type(2)));
+
+// TR rows of one lane through all kOvMax pivots of the block (the straight-line case).
+// The factors of pivot s + 1 are requested as soon as those of pivot s have arrived, so one scalar
+// load is in flight behind the TR multiply-subtract pairs of the current pivot.  The empty asm
+// pins that order by data dependence (it "reads" a factor of pivot s and "rewrites" the offset
+// the load of pivot s + 1 goes through); without it the compiler hoists all kOvMax loads to the
+// top of the chunk and spills them (2x the registers, measured in the ISA).
+template <int TR>
+__device__ __forceinline__ void ov_chunk(ov_v2d (&x)[TR], const ov_v2d (&p)[kOvMax],
+                                         const double* __restrict__ fci, int Rp) {
+    double fn[TR];
+#pragma unroll
+    for (int k = 0; k < TR; ++k) fn[k] = fci[k];  // wave-uniform: one scalar load
+#pragma unroll
+    for (int s = 0; s < kOvMax; ++s) {
+        double f[TR];
+#pragma unroll
+        for (int k = 0; k < TR; ++k) f[k] = fn[k];
+        if (s + 1 < kOvMax) {
+            size_t off = (size_t)(s + 1) * Rp;  // (the pointer itself must stay derived from the
+            asm volatile("" : "+s"(off) : "s"(f[0]));  // __restrict__ argument: scalar loads)
+#pragma unroll
+            for (int k = 0; k < TR; ++k) fn[k] = fci[off + k];
+        }
+#pragma unroll
+        for (int k = 0; k < TR; ++k) {
+            const double px = f[k] * p[s].x;  // product rounded ...
+            const double py = f[k] * p[s].y;
+            x[k].x = x[k].x - px;             // ... then the difference (:208)
+            x[k].y = x[k].y - py;
+        }
+        // pivot s is finished before the factors of pivot s + 2 are requested (program order kept)
+#pragma unroll
+        for (int k = 0; k < TR; ++k) asm volatile("" : "+v"(x[k]));
+    }
+}
+
 template <int TR, bool INPLACE>
-__device__ void ov_tiles(const OvBuffers B, int ld, int R, int Rp, int G, int lp) {
+__device__ __forceinline__ void ov_rows_load(ov_v2d (&x)[TR], const ov_v2d* src, int ld2) {
+#pragma unroll
+    for (int k = 0; k < TR; ++k) x[k] = INPLACE ? src[(size_t)k * ld2] : ov_ld_stream(&src[(size_t)k * ld2]);
+}
+
+template <int TR, bool INPLACE>
+__device__ __forceinline__ void ov_rows_store(const ov_v2d (&x)[TR], ov_v2d* dst, int ld2,
+                                              unsigned skip) {
+#pragma unroll
+    for (int k = 0; k < TR; ++k) {
+        if ((skip >> k) & 1u) continue;  // a pivot row of the block: recomputed afterwards
+        if (INPLACE) dst[(size_t)k * ld2] = x[k];
+        else __builtin_nontemporal_store(x[k], &dst[(size_t)k * ld2]);
+    }
+}
+
+// TR rows per chunk; DB: the next chunk's rows are requested before the current chunk is computed
+// (two register sets), so a wave always has loads in flight.
+template <int TR, bool DB, bool INPLACE>
+__device__ __forceinline__ void ov_tiles(const OvBuffers& B, const double* __restrict__ fcol,
+                                         const double* __restrict__ prow, int ld, int R, int Rp,
+                                         int G, int lp) {
+    typedef ov_v2d v2d;
+    static_assert(kOvTileRows % (2 * TR) == 0, "tile rows must be a multiple of two chunks");
     const OvCtl* ci = B.ctl + lp;
     const int tb = blockIdx.x - G;
     const int K = (ci->status == kRunning) ? ci->kdone : 0;
@@ -957,110 +1149,108 @@ __device__ void ov_tiles(const OvBuffers B, int ld, int R, int Rp, int G, int lp
         rt = nrt - 1 - rt;
     }
     const int c2 = ct * kOvNT + threadIdx.x;
-    // the factors f_s[i] of this tile's rows go through LDS: a broadcast read per (row, pivot)
-    // instead of a global load the compiler must order against the tile's own stores
-    __shared__ double s_f[kOvMax * kOvTileRows];
-    {
-        const double* fc = B.fcol + (size_t)ci->slot * kOvMax * Rp;
-        const int ibase = rt * kOvTileRows;
-        for (int idx = threadIdx.x; idx < K * kOvTileRows; idx += kOvNT) {
-            const int sidx = idx / kOvTileRows, j = idx % kOvTileRows;
-            s_f[idx] = (ibase + j < R) ? fc[(size_t)sidx * Rp + ibase + j] : 0.0;
-        }
-    }
-    __syncthreads();
     if (c2 >= ld2) return;
-    // in place every element is read and written by the same lane; out of place the buffers differ
-    const double2* Tin2 = reinterpret_cast<const double2*>(B.Tb[cur]);
-    double2* Tout2 = reinterpret_cast<double2*>(B.Tb[INPLACE ? cur : (cur ^ 1)]);
     const int sa = ci->slot;
-    const double2* __restrict__ prow2 =
-        reinterpret_cast<const double2*>(B.prow + (size_t)sa * kOvMax * ld);
-    int rr[kOvMax];
-    double2 p[kOvMax];  // this lane's slice of the K normalised pivot rows, for the whole tile
+    const double* __restrict__ fc = fcol + (size_t)sa * kOvMax * Rp;
+    const v2d* __restrict__ prow2 = reinterpret_cast<const v2d*>(prow + (size_t)sa * kOvMax * ld);
+    // in place every element is read and written by the same lane; out of place the buffers differ
+    const v2d* Tin2 = reinterpret_cast<const v2d*>(B.Tb[cur]);
+    v2d* Tout2 = reinterpret_cast<v2d*>(B.Tb[INPLACE ? cur : (cur ^ 1)]);
+    // this lane's slice of the normalised pivot rows, for the whole tile: all kOvMax loads in
+    // flight at once (rows >= K of the staging slot are stale but valid memory; they are not used)
+    v2d p[kOvMax];
 #pragma unroll
-    for (int s = 0; s < kOvMax; ++s) {
-        rr[s] = (s < K) ? ci->r[s] : -1;
-        p[s] = (s < K) ? prow2[(size_t)s * ld2 + c2] : make_double2(0.0, 0.0);
-    }
-    const int iend = min(R, (rt + 1) * kOvTileRows);
-    // The common tile: a full block of kOvMax pivots, all kOvTileRows rows present, no pivot row
-    // among them.  Nothing to test per (row, pivot) then, so the TR chains of a chunk are
-    // straight-line code the scheduler can interleave.
-    bool plain = (K == kOvMax) && (iend - rt * kOvTileRows == kOvTileRows);
+    for (int s = 0; s < kOvMax; ++s) p[s] = prow2[(size_t)s * ld2 + c2];
+    const int ibase = rt * kOvTileRows;
+    const int iend = min(R, ibase + kOvTileRows);
+
+    if (K == kOvMax && iend - ibase == kOvTileRows) {
+        // rows of this tile that are pivot rows of the block, as a bit mask (wave-uniform)
+        unsigned prmask = 0u;
 #pragma unroll
-    for (int s = 0; s < kOvMax; ++s)
-        plain = plain && !(rr[s] >= rt * kOvTileRows && rr[s] < iend);
-    if (plain) {
-        for (int i0 = rt * kOvTileRows; i0 < iend; i0 += TR) {
-            double2 x[TR];
-#pragma unroll
-            for (int k = 0; k < TR; ++k) {
-                const int i = i0 + k;
-                if (INPLACE) {
-                    x[k] = Tin2[(size_t)i * ld2 + c2];
-                } else {
-                    typedef double v2d __attribute__((ext_vector_type(2)));
-                    const v2d v = __builtin_nontemporal_load(
-                        reinterpret_cast<const v2d*>(&Tin2[(size_t)i * ld2 + c2]));
-                    x[k] = make_double2(v.x, v.y);
-                }
+        for (int s = 0; s < kOvMax; ++s) {
+            const int r = ci->r[s];
+            if (r >= ibase && r < iend) prmask |= 1u << (r - ibase);
+        }
+        const v2d* src = Tin2 + (size_t)ibase * ld2 + c2;
+        v2d* dst = Tout2 + (size_t)ibase * ld2 + c2;
+        const size_t step = (size_t)TR * ld2;
+        if (DB) {
+            v2d xa[TR], xb[TR];
+            ov_rows_load<TR, INPLACE>(xa, src, ld2);
+#pragma unroll 1
+            for (int j = 0; j < kOvTileRows; j += 2 * TR) {
+                ov_rows_load<TR, INPLACE>(xb, src + step, ld2);
+                ov_chunk<TR>(xa, p, fc + ibase + j, Rp);
+                ov_rows_store<TR, INPLACE>(xa, dst, ld2, prmask >> j);
+                if (j + 2 * TR < kOvTileRows) ov_rows_load<TR, INPLACE>(xa, src + 2 * step, ld2);
+                ov_chunk<TR>(xb, p, fc + ibase + j + TR, Rp);
+                ov_rows_store<TR, INPLACE>(xb, dst + step, ld2, prmask >> (j + TR));
+                src += 2 * step;
+                dst += 2 * step;
             }
-#pragma unroll
-            for (int s = 0; s < kOvMax; ++s) {
-#pragma unroll
-                for (int k = 0; k < TR; ++k) {
-                    const double f = s_f[s * kOvTileRows + (i0 - rt * kOvTileRows) + k];
-                    const double px = f * p[s].x;  // product rounded ...
-                    const double py = f * p[s].y;
-                    x[k].x = x[k].x - px;          // ... then the difference (:208)
-                    x[k].y = x[k].y - py;
-                }
+        } else {
+#pragma unroll 1
+            for (int j = 0; j < kOvTileRows; j += TR) {
+                v2d x[TR];
+                ov_rows_load<TR, INPLACE>(x, src, ld2);
+                ov_chunk<TR>(x, p, fc + ibase + j, Rp);
+                ov_rows_store<TR, INPLACE>(x, dst, ld2, prmask >> j);
+                src += step;
+                dst += step;
             }
+        }
+        if (prmask) {
 #pragma unroll
-            for (int k = 0; k < TR; ++k) {
-                const int i = i0 + k;
-                if (INPLACE) {
-                    Tout2[(size_t)i * ld2 + c2] = x[k];
-                } else {
-                    typedef double v2d __attribute__((ext_vector_type(2)));
-                    v2d v;
-                    v.x = x[k].x;
-                    v.y = x[k].y;
-                    __builtin_nontemporal_store(v, reinterpret_cast<v2d*>(&Tout2[(size_t)i * ld2 + c2]));
+            for (int s0 = 0; s0 < kOvMax; ++s0) {
+                const int i = ci->r[s0];
+                if (i < ibase || i >= iend) continue;
+                bool again = false;  // the row pivots again later in the block: that one stores it
+#pragma unroll
+                for (int s1 = s0 + 1; s1 < kOvMax; ++s1) again = again || (ci->r[s1] == i);
+                if (again) continue;
+                v2d t = p[s0];  // the pivot row keeps the normalised values (:199) ...
+#pragma unroll
+                for (int s1 = s0 + 1; s1 < kOvMax; ++s1) {  // ... and is an ordinary row afterwards
+                    const double f = fc[(size_t)s1 * Rp + i];
+                    const double px = f * p[s1].x;
+                    const double py = f * p[s1].y;
+                    t.x = t.x - px;
+                    t.y = t.y - py;
                 }
+                v2d* d = &Tout2[(size_t)i * ld2 + c2];
+                if (INPLACE) *d = t;
+                else __builtin_nontemporal_store(t, d);
             }
         }
         return;
     }
-    for (int i0 = rt * kOvTileRows; i0 < iend; i0 += TR) {  // TR rows in flight per lane
-        double2 x[TR];
+    // partial blocks (the last block of a solve) and the ragged last row tile
+    int rr[kOvMax];
+#pragma unroll
+    for (int s = 0; s < kOvMax; ++s) rr[s] = (s < K) ? ci->r[s] : -1;
+    for (int i0 = ibase; i0 < iend; i0 += TR) {  // TR rows in flight per lane
+        v2d x[TR];
 #pragma unroll
         for (int k = 0; k < TR; ++k) {
             const int i = i0 + k;
             if (i < iend) {
-                if (INPLACE) {
-                    x[k] = Tin2[(size_t)i * ld2 + c2];
-                } else {  // streamed once: keep it out of the caches the heads live in
-                    typedef double v2d __attribute__((ext_vector_type(2)));
-                    const v2d v = __builtin_nontemporal_load(
-                        reinterpret_cast<const v2d*>(&Tin2[(size_t)i * ld2 + c2]));
-                    x[k] = make_double2(v.x, v.y);
-                }
+                const v2d* src = &Tin2[(size_t)i * ld2 + c2];
+                x[k] = INPLACE ? *src : ov_ld_stream(src);
             }
         }
 #pragma unroll
         for (int k = 0; k < TR; ++k) {
             const int i = i0 + k;
             if (i < iend) {
-                double2 t = x[k];
+                v2d t = x[k];
 #pragma unroll
                 for (int s = 0; s < kOvMax; ++s) {
                     if (s < K) {
                         if (i == rr[s]) {
                             t = p[s];  // the pivot row keeps the normalised values (:199)
                         } else {
-                            const double f = s_f[s * kOvTileRows + (i - rt * kOvTileRows)];
+                            const double f = fc[(size_t)s * Rp + i];
                             const double px = f * p[s].x;  // product rounded ...
                             const double py = f * p[s].y;
                             t.x = t.x - px;                // ... then the difference (:208)
@@ -1068,56 +1258,59 @@ __device__ void ov_tiles(const OvBuffers B, int ld, int R, int Rp, int G, int lp
                         }
                     }
                 }
-                if (INPLACE) {
-                    Tout2[(size_t)i * ld2 + c2] = t;
-                } else {
-                    typedef double v2d __attribute__((ext_vector_type(2)));
-                    v2d v;
-                    v.x = t.x;
-                    v.y = t.y;
-                    __builtin_nontemporal_store(v, reinterpret_cast<v2d*>(&Tout2[(size_t)i * ld2 + c2]));
-                }
+                v2d* dst = &Tout2[(size_t)i * ld2 + c2];
+                if (INPLACE) *dst = t;
+                else __builtin_nontemporal_store(t, dst);
             }
         }
     }
 }
 
-template <int TR>
-__global__ __launch_bounds__(kOvNT) void k_ov_step(const OvBuffers B, int ld, int R, int C, int Rp,
-                                                   int K, int G, int lp) {
+template <int TR, bool DB>
+__global__ __launch_bounds__(kOvNT) void k_ov_step(const OvBuffers B,
+                                                   const double* __restrict__ fcol_ro,
+                                                   const double* __restrict__ prow_ro, int ld,
+                                                   int R, int C, int Rp, int K, int G, int lp) {
+    // fcol_ro / prow_ro alias B.fcol / B.prow, which the heads of this launch write -- but only the
+    // OTHER staging slot (ci->slot ^ 1) than the one the tiles read, so the read-only view holds
     if ((int)blockIdx.x < G)
         ov_heads<kOvNT>(B, ld, R, C, Rp, K, G, lp, false);
     else
-        ov_tiles<TR, false>(B, ld, R, Rp, G, lp);
+        ov_tiles<TR, DB, false>(B, fcol_ro, prow_ro, ld, R, Rp, G, lp);
 }
 
 // The two halves as separate kernels on two streams, running concurrently (variant 0x30tr): same
 // protocol as k_ov_step, but each kernel has its own register budget (in k_ov_step the heads'
 // registers cap the occupancy of the sweep's tiles and vice versa).
-template <int NT>
+template <int NT, bool STAMP>
 __global__ __launch_bounds__(NT) void k_ov2_heads(const OvBuffers B, int ld, int R, int C, int Rp,
-                                                  int K, int G, int lp) {
-    ov_heads_rich<NT>(B, ld, R, C, Rp, K, G, lp, false);
+                                                  int K, int G, int lp, int spread, int no_l2) {
+    ov_heads_rich<NT, STAMP>(B, ld, R, C, Rp, K, G, lp, false, spread, no_l2);
 }
 
-template <int TR>
-__global__ __launch_bounds__(kOvNT) void k_ov2_sweep(const OvBuffers B, int ld, int R, int Rp,
-                                                     int lp) {
-    ov_tiles<TR, false>(B, ld, R, Rp, 0, lp);
+template <int TR, bool DB>
+__global__ __launch_bounds__(kOvNT) void k_ov2_sweep(const OvBuffers B,
+                                                     const double* __restrict__ fcol_ro,
+                                                     const double* __restrict__ prow_ro, int ld,
+                                                     int R, int Rp, int lp) {
+    ov_tiles<TR, DB, false>(B, fcol_ro, prow_ro, ld, R, Rp, 0, lp);
 }
 
 // The same two halves as separate launches: all K loop heads of a block in ONE persistent launch
 // (no sweep running: nothing to chain through but the block's own pivots), then the sweep in
 // place.  Heads always run on control block 0, the sweep on control block 1.
-template <int NT>
+template <int NT, bool STAMP>
 __global__ __launch_bounds__(NT) void k_ov_heads(const OvBuffers B, int ld, int R, int C, int Rp,
-                                                 int K, int G) {
-    ov_heads_rich<NT>(B, ld, R, C, Rp, K, G, 0, true);
+                                                 int K, int G, int spread, int no_l2) {
+    ov_heads_rich<NT, STAMP>(B, ld, R, C, Rp, K, G, 0, true, spread, no_l2);
 }
 
-template <int TR>
-__global__ __launch_bounds__(kOvNT) void k_ov_sweep(const OvBuffers B, int ld, int R, int Rp) {
-    ov_tiles<TR, true>(B, ld, R, Rp, 0, 1);
+template <int TR, bool DB>
+__global__ __launch_bounds__(kOvNT) void k_ov_sweep(const OvBuffers B,
+                                                    const double* __restrict__ fcol_ro,
+                                                    const double* __restrict__ prow_ro, int ld,
+                                                    int R, int Rp) {
+    ov_tiles<TR, DB, true>(B, fcol_ro, prow_ro, ld, R, Rp, 0, 1);
 }
 
 }  // namespace lpr
@@ -1129,6 +1322,7 @@ struct lpr_overlap_ctx {
     int rows = 0, ld = 0, Rp = 0;
     lpr::OvBuffers b{};
     lpr::OvCtl* h_ctl = nullptr;  // pinned, 2 entries
+    double* h_z = nullptr;        // pinned, 2 entries
     double* T2 = nullptr;         // the second tableau buffer (owned here)
     hipStream_t hstream = nullptr;  // the heads' stream of the two-stream variant
     hipEvent_t ev_h[2] = {nullptr, nullptr}, ev_s[2] = {nullptr, nullptr};
@@ -1136,6 +1330,12 @@ struct lpr_overlap_ctx {
 };
 
 namespace lpr {
+
+struct OvPoll {
+    int32_t status, pending, kdone, cur, error;
+    int64_t applied;
+    double z[2];
+};
 
 int ov_max_pivots() { return kOvMax; }
 
@@ -1158,9 +1358,12 @@ void ov_release(lpr_tableau* t) {
     hipFree(c->b.zparts);
     hipFree(c->b.rparts);
     hipFree(c->b.gran);
+    hipFree(c->b.xgran);
+    hipFree(c->b.dbg);
     hipFree(c->b.ctl);
     hipFree(c->b.bar);
     if (c->h_ctl) hipHostFree(c->h_ctl);
+    if (c->h_z) hipHostFree(c->h_z);
     delete c;
     t->ov = nullptr;
 }
@@ -1187,9 +1390,12 @@ int ov_ensure(lpr_tableau* t, bool second_buffer) {
     chk(hipMalloc(&c->b.zparts, (size_t)2 * kOvGroups * sizeof(ZPart)));
     chk(hipMalloc(&c->b.rparts, (size_t)(3 * kOvGroups + 1) * sizeof(double)));
     chk(hipMalloc(&c->b.gran, (size_t)9 * kOvGroups * sizeof(unsigned long long)));
+    chk(hipMalloc(&c->b.xgran, (size_t)kOvGroups * sizeof(unsigned long long)));
+    chk(hipMalloc(&c->b.dbg, kOvDbgWords * sizeof(unsigned long long)));
     chk(hipMalloc(&c->b.ctl, 2 * sizeof(OvCtl)));
     chk(hipMalloc(&c->b.bar, 4 * sizeof(unsigned)));
     chk(hipHostMalloc(&c->h_ctl, 2 * sizeof(OvCtl)));
+    chk(hipHostMalloc(&c->h_z, 2 * sizeof(double)));
     t->ov = c;
     if (err != hipSuccess) {
         set_error("overlapped-pivot scratch allocation failed: %s", hipGetErrorString(err));
@@ -1203,8 +1409,17 @@ int ov_ensure(lpr_tableau* t, bool second_buffer) {
     LPR_HIP(hipMemsetAsync(c->b.zrow, 0, (size_t)c->ld * D, s));
     LPR_HIP(hipMemsetAsync(c->b.bvec, 0, (size_t)2 * c->Rp * D, s));
     LPR_HIP(hipMemsetAsync(c->b.zparts, 0, (size_t)2 * kOvGroups * sizeof(ZPart), s));
+    LPR_HIP(hipMemsetAsync(c->b.dbg, 0, kOvDbgWords * sizeof(unsigned long long), s));
     std::memset(c->h_ctl, 0, 2 * sizeof(OvCtl));
     return LPR_OK_OPTIMAL;
+}
+
+// sweep tile code (low byte of opts.variant): rows per chunk, + 0x20 = two chunks in flight
+static int ov_tile_code(int tr) {
+    switch (tr) {
+        case 0x04: case 0x10: case 0x24: case 0x28: return tr;
+        default: return 0x08;
+    }
 }
 
 static int ov_groups(const lpr_tableau* t) {
@@ -1232,12 +1447,11 @@ int ov_begin(lpr_tableau* t, int64_t iter, int64_t max_iter) {
     h[0].log_cap = t->log_cap;
     h[1] = h[0];
     LPR_HIP(hipMemcpyAsync(c->b.ctl, h, 2 * sizeof(OvCtl), hipMemcpyHostToDevice, s));
-    LPR_HIP(hipMemsetAsync(c->b.bar, 0, 4 * sizeof(unsigned), s));
-    LPR_HIP(hipMemsetAsync(c->b.gran, 0, (size_t)9 * kOvGroups * sizeof(unsigned long long), s));
     hipLaunchKernelGGL(k_ov_prologue, dim3(1), dim3(1024), 0, s, t->T, t->ld, t->rows, t->cols,
                        c->b.zrow, c->b.bvec + (size_t)(iter & 1) * c->Rp,
                        c->b.zparts + (iter & 1) * kOvGroups, ov_groups(t),
-                       c->b.gran + (size_t)(iter & 1) * 3 * kOvGroups, (unsigned)(2 * iter + 1));
+                       c->b.gran + (size_t)(iter & 1) * 3 * kOvGroups, (unsigned)(2 * iter + 1),
+                       c->b.gran, c->b.xgran, c->b.bar);
     LPR_HIP(hipGetLastError());
     return LPR_OK_OPTIMAL;
 }
@@ -1259,26 +1473,31 @@ void ov_launch_step(lpr_tableau* t, int K, int tr, int lp) {
     const int ld2 = t->ld / 2;
     const int nct = (ld2 + kOvNT - 1) / kOvNT;
     const int nrt = (t->rows + kOvTileRows - 1) / kOvTileRows;
-    if (tr >= 16)
-        hipLaunchKernelGGL((k_ov_step<16>), dim3(G + nct * nrt), dim3(kOvNT), 0, s, c->b, t->ld,
-                           t->rows, t->cols, c->Rp, K, G, lp);
-    else if (tr >= 8)
-        hipLaunchKernelGGL((k_ov_step<8>), dim3(G + nct * nrt), dim3(kOvNT), 0, s, c->b, t->ld,
-                           t->rows, t->cols, c->Rp, K, G, lp);
-    else
-        hipLaunchKernelGGL((k_ov_step<4>), dim3(G + nct * nrt), dim3(kOvNT), 0, s, c->b, t->ld,
-                           t->rows, t->cols, c->Rp, K, G, lp);
+    const dim3 grid(G + nct * nrt), blk(kOvNT);
+#define LPR_OV_STEP(TR, DB)                                                                      \
+    hipLaunchKernelGGL((k_ov_step<TR, DB>), grid, blk, 0, s, c->b, c->b.fcol, c->b.prow, t->ld,   \
+                       t->rows, t->cols, c->Rp, K, G, lp)
+    if (tr >= 16) LPR_OV_STEP(16, false);
+    else if (tr >= 8) LPR_OV_STEP(8, false);
+    else LPR_OV_STEP(4, false);
+#undef LPR_OV_STEP
 }
 
-void ov_launch_heads(lpr_tableau* t, int K) {
+// flags (opts.variant >> 16): 1 = diagnostic time stamps, 2 = do not confine the heads to one XCD
+// (one workgroup per group, memory-side hand-offs: the round-1 form), 4 = confine them but keep
+// the memory-side hand-offs.
+void ov_launch_heads(lpr_tableau* t, int K, int flags) {
     lpr_overlap_ctx* c = static_cast<lpr_overlap_ctx*>(t->ov);
-    const int nt = kOvNT;  // 512 measures the same, 1024 slower
-    int G = (t->ld / 2 + nt - 1) / nt;
-    if (G < 1) G = 1;
-    if (G > kOvGroups) G = kOvGroups;
+    const int G = ov_groups(t);  // 256 lanes per group; 512 measures the same, 1024 slower
+    const int spread = (flags & 2) ? 1 : 8;
+    const int no_l2 = (flags & 6) ? 1 : 0;
     hipStream_t s = t->eng->stream;
-    hipLaunchKernelGGL((k_ov_heads<kOvNT>), dim3(G), dim3(kOvNT), 0, s, c->b, t->ld, t->rows,
-                       t->cols, c->Rp, K, G);
+    if (flags & 1)
+        hipLaunchKernelGGL((k_ov_heads<kOvNT, true>), dim3(G * spread), dim3(kOvNT), 0, s, c->b,
+                           t->ld, t->rows, t->cols, c->Rp, K, G, spread, no_l2);
+    else
+        hipLaunchKernelGGL((k_ov_heads<kOvNT, false>), dim3(G * spread), dim3(kOvNT), 0, s, c->b,
+                           t->ld, t->rows, t->cols, c->Rp, K, G, spread, no_l2);
 }
 
 void ov_launch_sweep(lpr_tableau* t, int tr) {
@@ -1286,15 +1505,18 @@ void ov_launch_sweep(lpr_tableau* t, int tr) {
     hipStream_t s = t->eng->stream;
     const int nct = (t->ld / 2 + kOvNT - 1) / kOvNT;
     const int nrt = (t->rows + kOvTileRows - 1) / kOvTileRows;
-    if (tr >= 16)
-        hipLaunchKernelGGL((k_ov_sweep<16>), dim3(nct * nrt), dim3(kOvNT), 0, s, c->b, t->ld,
-                           t->rows, c->Rp);
-    else if (tr >= 8)
-        hipLaunchKernelGGL((k_ov_sweep<8>), dim3(nct * nrt), dim3(kOvNT), 0, s, c->b, t->ld,
-                           t->rows, c->Rp);
-    else
-        hipLaunchKernelGGL((k_ov_sweep<4>), dim3(nct * nrt), dim3(kOvNT), 0, s, c->b, t->ld,
-                           t->rows, c->Rp);
+    const dim3 grid(nct * nrt), blk(kOvNT);
+#define LPR_OV_SWEEP(TR, DB)                                                                     \
+    hipLaunchKernelGGL((k_ov_sweep<TR, DB>), grid, blk, 0, s, c->b, c->b.fcol, c->b.prow, t->ld,  \
+                       t->rows, c->Rp)
+    switch (ov_tile_code(tr)) {
+        case 0x04: LPR_OV_SWEEP(4, false); break;
+        case 0x10: LPR_OV_SWEEP(16, false); break;
+        case 0x24: LPR_OV_SWEEP(4, true); break;
+        case 0x28: LPR_OV_SWEEP(8, true); break;
+        default: LPR_OV_SWEEP(8, false); break;
+    }
+#undef LPR_OV_SWEEP
 }
 
 // two-stream variant: heads on their own (high-priority) stream, sweep on the engine stream.
@@ -1317,27 +1539,39 @@ int ov2_begin(lpr_tableau* t) {
     return LPR_OK_OPTIMAL;
 }
 
-int ov2_launch_step(lpr_tableau* t, int K, int tr, int lp) {
+int ov2_launch_step(lpr_tableau* t, int K, int tr, int lp, int flags, hipEvent_t ev_start,
+                    hipEvent_t ev_stop) {
     lpr_overlap_ctx* c = static_cast<lpr_overlap_ctx*>(t->ov);
     hipStream_t S = t->eng->stream, H = c->hstream;
     const int cur = c->ev_idx, prev = cur ^ 1;
     LPR_HIP(hipStreamWaitEvent(H, c->ev_s[prev], 0));
     LPR_HIP(hipStreamWaitEvent(S, c->ev_h[prev], 0));
+    if (ev_start) LPR_HIP(hipEventRecord(ev_start, S));  // both kernels of the previous step done
     const int G = ov_groups(t);
-    hipLaunchKernelGGL((k_ov2_heads<kOvNT>), dim3(G), dim3(kOvNT), 0, H, c->b, t->ld, t->rows,
-                       t->cols, c->Rp, K, G, lp);
+    const int spread = (flags & 2) ? 1 : 8;
+    const int no_l2 = (flags & 6) ? 1 : 0;
+    if (flags & 1)
+        hipLaunchKernelGGL((k_ov2_heads<kOvNT, true>), dim3(G * spread), dim3(kOvNT), 0, H, c->b,
+                           t->ld, t->rows, t->cols, c->Rp, K, G, lp, spread, no_l2);
+    else
+        hipLaunchKernelGGL((k_ov2_heads<kOvNT, false>), dim3(G * spread), dim3(kOvNT), 0, H, c->b,
+                           t->ld, t->rows, t->cols, c->Rp, K, G, lp, spread, no_l2);
     LPR_HIP(hipEventRecord(c->ev_h[cur], H));
     const int nct = (t->ld / 2 + kOvNT - 1) / kOvNT;
     const int nrt = (t->rows + kOvTileRows - 1) / kOvTileRows;
-    if (tr >= 16)
-        hipLaunchKernelGGL((k_ov2_sweep<16>), dim3(nct * nrt), dim3(kOvNT), 0, S, c->b, t->ld,
-                           t->rows, c->Rp, lp);
-    else if (tr >= 8)
-        hipLaunchKernelGGL((k_ov2_sweep<8>), dim3(nct * nrt), dim3(kOvNT), 0, S, c->b, t->ld,
-                           t->rows, c->Rp, lp);
-    else
-        hipLaunchKernelGGL((k_ov2_sweep<4>), dim3(nct * nrt), dim3(kOvNT), 0, S, c->b, t->ld,
-                           t->rows, c->Rp, lp);
+    const dim3 grid(nct * nrt), blk(kOvNT);
+#define LPR_OV2_SWEEP(TR, DB)                                                                    \
+    hipLaunchKernelGGL((k_ov2_sweep<TR, DB>), grid, blk, 0, S, c->b, c->b.fcol, c->b.prow, t->ld, \
+                       t->rows, c->Rp, lp)
+    switch (ov_tile_code(tr)) {
+        case 0x04: LPR_OV2_SWEEP(4, false); break;
+        case 0x10: LPR_OV2_SWEEP(16, false); break;
+        case 0x24: LPR_OV2_SWEEP(4, true); break;
+        case 0x28: LPR_OV2_SWEEP(8, true); break;
+        default: LPR_OV2_SWEEP(8, false); break;
+    }
+#undef LPR_OV2_SWEEP
+    if (ev_stop) LPR_HIP(hipEventRecord(ev_stop, S));  // this step's sweep done
     LPR_HIP(hipEventRecord(c->ev_s[cur], S));
     c->ev_idx = prev;
     return LPR_OK_OPTIMAL;
@@ -1350,17 +1584,43 @@ int ov2_join(lpr_tableau* t) {
     return LPR_OK_OPTIMAL;
 }
 
-// reads control block `parity` back
-int ov_poll(lpr_tableau* t, int parity, int32_t* status, int32_t* cur, int64_t* applied,
-            int32_t* error) {
+// reads control block `parity` back, and entry 0 of both RHS-column buffers (= T[0, cols-1] after
+// an even / odd number of pivots): one synchronisation per poll
+int ov_poll(lpr_tableau* t, int parity, OvPoll* out) {
     lpr_overlap_ctx* c = static_cast<lpr_overlap_ctx*>(t->ov);
     hipStream_t s = t->eng->stream;
     LPR_HIP(hipMemcpyAsync(c->h_ctl, c->b.ctl, 2 * sizeof(OvCtl), hipMemcpyDeviceToHost, s));
+    LPR_HIP(hipMemcpyAsync(&c->h_z[0], c->b.bvec, sizeof(double), hipMemcpyDeviceToHost, s));
+    LPR_HIP(hipMemcpyAsync(&c->h_z[1], c->b.bvec + c->Rp, sizeof(double), hipMemcpyDeviceToHost,
+                           s));
     LPR_HIP(hipStreamSynchronize(s));
-    *status = c->h_ctl[parity].status;
-    *cur = c->h_ctl[parity].cur;
-    *applied = c->h_ctl[parity].applied;
-    *error = c->h_ctl[parity].error;
+    const OvCtl& h = c->h_ctl[parity];
+    out->status = h.status;
+    out->pending = h.pending;
+    out->kdone = h.kdone;
+    out->cur = h.cur;
+    out->error = h.error;
+    out->applied = h.applied;
+    out->z[0] = c->h_z[0];
+    out->z[1] = c->h_z[1];
+    return LPR_OK_OPTIMAL;
+}
+
+// diagnostic: the stamps of the lead head workgroup (ring of kOvStampPivots pivots x
+// kOvStampsPerPivot, 10 ns ticks), then its XCC id and the hand-off mode of its last launch
+int ov_read_stamps(lpr_tableau* t, uint64_t* out, int64_t cap, int64_t* count) {
+    lpr_overlap_ctx* c = static_cast<lpr_overlap_ctx*>(t->ov);
+    if (!c) {
+        *count = 0;
+        return LPR_OK_OPTIMAL;
+    }
+    int64_t n = (int64_t)kOvDbgWords;
+    if (n > cap) n = cap;
+    *count = n;
+    if (n > 0 && out) {
+        LPR_HIP(hipStreamSynchronize(t->eng->stream));
+        LPR_HIP(hipMemcpy(out, c->b.dbg, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    }
     return LPR_OK_OPTIMAL;
 }
 

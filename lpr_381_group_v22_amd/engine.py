@@ -215,6 +215,23 @@ class Tableau:
                 "lpr_tableau_kernel_stats")
         return n.value, tot.value, avg.value
 
+    def step_stats(self) -> Tuple[int, float]:
+        """(steps timed, summed milliseconds): a step = one sweep of K pivots beside the loop
+        heads of the next K (K-pivot paths with time_kernels)."""
+        n, tot = C.c_int64(), C.c_double()
+        N.check(N.lib.lpr_tableau_step_stats(self._h, C.byref(n), C.byref(tot)),
+                "lpr_tableau_step_stats")
+        return n.value, tot.value
+
+    def head_stamps(self):
+        """Diagnostic stamps of the lead loop-head workgroup (variant bit 16): (array of shape
+        (64, 12) in 10 ns ticks, XCC id, 1 if the hand-offs went through the XCD's L2)."""
+        buf = np.zeros(64 * 12 + 8, dtype=np.uint64)
+        cnt = C.c_int64()
+        N.check(N.lib.lpr_debug_head_stamps(self._h, buf.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                            buf.size, C.byref(cnt)), "lpr_debug_head_stamps")
+        return buf[:64 * 12].reshape(64, 12), int(buf[64 * 12]), int(buf[64 * 12 + 1])
+
 
 class RevisedState:
     """Device-resident state of the revised primal simplex (lpr_revised_*)."""

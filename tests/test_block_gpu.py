@@ -16,11 +16,23 @@ import lp_cases
 pytestmark = pytest.mark.gpu
 
 SEQ, OV, INPLACE, OV2 = 0x4008, 0x5008, 0x6008, 0x3008
-NAMES = {SEQ: "seq", OV: "ov", INPLACE: "inplace", OV2: "ov2"}
+# bits 16..18 of the variant (K-pivot paths): the loop heads are normally confined to one XCD and
+# hand off through its L2 when the launch finds them there; SPREAD = one workgroup per group
+# anywhere on the chip with memory-side hand-offs (the round-1 form), MEMSIDE = confined but
+# memory-side hand-offs, STAMPS = the diagnostic build.  Same bits every way.
+STAMPS, SPREAD, MEMSIDE = 0x10000, 0x20000, 0x40000
+NAMES = {SEQ: "seq", OV: "ov", INPLACE: "inplace", OV2: "ov2",
+         SEQ | SPREAD: "seq-spread", OV2 | SPREAD: "ov2-spread", OV2 | MEMSIDE: "ov2-memside",
+         SEQ | STAMPS: "seq-stamps", OV2 | STAMPS: "ov2-stamps",
+         0x3024: "ov2-2x4", 0x3028: "ov2-2x8", 0x3004: "ov2-4", 0x3010: "ov2-16",
+         0x4024: "seq-2x4", 0x4028: "seq-2x8", 0x4010: "seq-16"}
 # (variant, block)
 BLOCKS = [(SEQ, 2), (SEQ, 5), (SEQ, 8), (SEQ, 16), (OV, 2), (OV, 3), (OV, 8), (OV, 16),
           (OV2, 2), (OV2, 7), (OV2, 16),
-          (INPLACE, 2), (INPLACE, 4), (INPLACE, 8)]
+          (INPLACE, 2), (INPLACE, 4), (INPLACE, 8),
+          (SEQ | SPREAD, 16), (OV2 | SPREAD, 16), (OV2 | MEMSIDE, 9), (SEQ | STAMPS, 16),
+          (OV2 | STAMPS, 13), (0x3024, 16), (0x3028, 16), (0x3004, 16), (0x3010, 16),
+          (0x4024, 16), (0x4028, 11), (0x4010, 16)]
 IDS = [NAMES[v] + str(b) for v, b in BLOCKS]
 
 
@@ -291,4 +303,117 @@ def test_random_wide_lps_many_head_groups(engine, oracle):
             assert tab.read().tobytes() == T.tobytes(), tag
             if st != 5:
                 break
+        tab.destroy()
+
+
+def _north_star_oracle(oracle, pivots):
+    m, n, seed = 4096, 8192, 0
+    T, basis = oracle.gen_dense_tableau(m, n, seed)
+    st, piv, log = oracle.primal_solve(T, basis, pivots)
+    assert st == 5 and piv == pivots
+    return st, log, basis, hashlib.sha256(T.tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def north_star_64(oracle):
+    return _north_star_oracle(oracle, 64)
+
+
+@pytest.mark.parametrize("variant", [0, SPREAD, MEMSIDE, 0x4008, 0x5008, 0x3024, 0x3028, 0x3004],
+                         ids=["default", "default-spread", "default-memside", "seq", "ov",
+                              "ov2-2x4", "ov2-2x8", "ov2-4"])
+def test_north_star_size_64_pivots_vs_oracle(engine, north_star_64, variant):
+    """BASELINE's headline size (m=4096, n=8192: 4097 x 12289, 25 loop-head workgroups): four full
+    blocks of 16 -- from the second on, the next block's heads run beside the sweep -- against the
+    ORACLE: status, pivot log, basis and the sha256 of all 402.8 MB of the tableau.  The default
+    is the two-stream path with the heads confined to one XCD."""
+    from lpr_381_group_v22_amd import Tableau
+    st, log, basis, sha = north_star_64
+    tab = Tableau.synthetic(engine, 4096, 8192, 0)
+    res = tab.solve(max_pivots=64, variant=variant)
+    assert res.status == st and res.pivots == 64 and res.block == 16
+    assert tab.pivot_log().tolist() == log.tolist()
+    assert tab.basis().tolist() == basis.tolist()
+    assert hashlib.sha256(tab.read().tobytes()).hexdigest() == sha
+    tab.destroy()
+
+
+def test_north_star_size_ragged_legs_vs_oracle(engine, oracle):
+    """The same size in legs that cut blocks (1 + 37 + 32 pivots, the bench's probe / warm-up /
+    timed pattern) with kernel timing on: the tableau after 70 pivots equals the oracle's."""
+    from lpr_381_group_v22_amd import Tableau
+    st, log, basis, sha = _north_star_oracle(oracle, 70)
+    tab = Tableau.synthetic(engine, 4096, 8192, 0)
+    total = 0
+    for leg, timed in ((1, False), (37, False), (32, True)):
+        res = tab.solve(max_pivots=leg, time_kernels=timed)
+        total += res.pivots
+        assert res.status == 5 and res.pivots == leg and res.total_pivots == total
+    launches, total_ms, avg_ms = tab.kernel_stats()
+    steps, step_ms = tab.step_stats()
+    assert launches == 2 and steps == 2 and 0 < total_ms <= step_ms
+    assert tab.pivot_log().tolist() == log.tolist()
+    assert tab.basis().tolist() == basis.tolist()
+    assert hashlib.sha256(tab.read().tobytes()).hexdigest() == sha
+    tab.destroy()
+
+
+def test_head_placement_report(engine):
+    """Diagnostic build of the loop heads (variant bit 16): stamps are monotone per pivot and the
+    launch reports where the lead workgroup ran and which hand-off form it chose."""
+    from lpr_381_group_v22_amd import Tableau
+    tab = Tableau.synthetic(engine, 4096, 8192, 0)
+    res = tab.solve(max_pivots=48, variant=STAMPS)
+    assert res.pivots == 48
+    stamps, xcc, l2 = tab.head_stamps()
+    assert 0 <= xcc < 8 and l2 in (0, 1)
+    used = stamps[:48]
+    assert (used[:, 0] > 0).all()
+    assert (np.diff(used.astype(np.int64), axis=1) >= 0).all()
+    tab.destroy()
+
+
+def test_interleaved_paths_on_one_handle(engine, oracle):
+    """One tableau handle through the one-pivot graph path, the fused small-tableau path (odd pivot
+    counts swap its two buffers), the two-stream and in-place K-pivot paths and back: a captured
+    graph must never be replayed on buffers it was not captured for."""
+    from lpr_381_group_v22_amd import Tableau
+    m, n, seed = 60, 90, 4
+    T, basis = oracle.gen_dense_tableau(m, n, seed)
+    tab = Tableau.synthetic(engine, m, n, seed)
+    total = 0
+    legs = [(0x7fff, 1, 6), (0x7ffe, 1, 5), (0x7fff, 1, 6), (OV2, 4, 7), (0x7fff, 1, 6),
+            (0x7ffe, 1, 3), (INPLACE, 3, 5), (0x7fff, 1, 6), (SEQ, 16, 9), (0, 0, 4),
+            (0x7fff, 1, 6)]
+    for variant, block, limit in legs:
+        st, piv, log = oracle.primal_solve(T, basis, limit)
+        res = tab.solve(max_pivots=limit, variant=variant, block=block, batch=6)
+        total += piv
+        tag = (hex(variant), block, limit)
+        assert res.status == st and res.pivots == piv and res.total_pivots == total, tag
+        assert tab.pivot_log().tolist()[total - piv:] == log.tolist(), tag
+        assert tab.basis().tolist() == basis.tolist(), tag
+        assert tab.read().tobytes() == T.tobytes(), tag
+        if st != 5:
+            break
+    tab.destroy()
+
+
+def test_ratio_that_overflows_is_not_a_candidate(engine, oracle):
+    """FindLeavingVariable (:184) takes a row only when ratio < minRatio, which starts at
+    double.MaxValue: rhs / a = +inf (or exactly MaxValue) never qualifies -> "unbounded"."""
+    from lpr_381_group_v22_amd import Tableau
+    T = np.array([[-1.0, 0.0, 0.0, 0.0],
+                  [1e-8, 1.0, 0.0, 1e308],         # a > 1e-9; 1e308 / 1e-8 = +inf
+                  [2.0 ** -29, 0.0, 1.0, 2.0 ** 994 * (2.0 - 2.0 ** -52)]], dtype=np.float64)
+    # second row: ratio == DBL_MAX exactly ((2 - 2^-52) * 2^1023): not < MaxValue either
+    assert T[2, 3] / T[2, 0] == np.finfo(np.float64).max and T[1, 3] / T[1, 0] == np.inf
+    for variant, block in ((0x7fff, 1), (0x7ffe, 1), (SEQ, 4), (OV2, 4), (OV, 4), (INPLACE, 4)):
+        Tc, basis = T.copy(), np.array([1, 2], dtype=np.int32)
+        st, piv, log = oracle.primal_solve(Tc, basis, 10)
+        assert st == 1 and piv == 0
+        tab = Tableau.from_array(engine, T, [1, 2])
+        res = tab.solve(max_pivots=10, variant=variant, block=block)
+        assert res.status == 1 and res.pivots == 0, hex(variant)
+        assert tab.read().tobytes() == Tc.tobytes()
         tab.destroy()

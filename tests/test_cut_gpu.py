@@ -83,3 +83,32 @@ def test_cut_path_then_primal_path_on_grown_tableau(engine, oracle):
     assert res.status == st and res.pivots == piv
     assert tab.read().tobytes() == T.tobytes()
     tab.destroy()
+
+
+def test_solve_cut_solve_cut_solve_on_one_handle(engine, oracle):
+    """lpr_primal_solve (one-pivot path: captured graph) / lpr_cutting_plane alternating on one
+    handle: every cut adds a row (and may or may not re-allocate), so a graph captured for the old
+    row count must not be replayed; each leg is checked against the oracle."""
+    from lpr_381_group_v22_amd import Tableau
+    checked = 0
+    for name, T0 in cut_cases.cutting_plane_tableaux(oracle)[:4]:
+        T = T0.copy()
+        tab = Tableau.from_array(engine, T0)
+        for leg in range(3):
+            st, piv, plog = oracle.primal_solve(T, None, 40)
+            res = tab.solve(max_pivots=40, variant=0x7fff, batch=4)   # two-kernel graph path
+            assert res.status == st and res.pivots == piv, (name, leg)
+            assert tab.read().tobytes() == T.tobytes(), (name, leg)
+            rc, cuts, T, log = oracle.cutting_plane(T, max_cuts=1, hard_cap=2000)
+            ex, ncuts = tab.cutting_plane(max_cuts=1, hard_cap=2000)
+            assert (ex, ncuts) == (rc, cuts), (name, leg)
+            got = tab.read()
+            assert got.shape == T.shape and got.tobytes() == T.tobytes(), (name, leg)
+            checked += 1
+        # and through the K-pivot path on the grown tableau
+        st, piv, plog = oracle.primal_solve(T, None, 40)
+        res = tab.solve(max_pivots=40, variant=0x4008, block=4)
+        assert res.status == st and res.pivots == piv, name
+        assert tab.read().tobytes() == T.tobytes(), name
+        tab.destroy()
+    assert checked >= 9

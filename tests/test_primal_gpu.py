@@ -282,3 +282,32 @@ def test_fused_and_pipelined_paths_agree(engine, oracle, m, n, seed):
         xr, zr = oracle.extract_solution(T, n)
         assert x.tobytes() == xr.tobytes() and z == zr
         tab.destroy()
+
+
+def test_handles_outlive_their_engine_safely():
+    """lpr_engine_close releases what the caller forgot and orphans the handles: a later call on one
+    of them is LPR_BAD_ARGUMENT (no crash, the exit-139 of round 1), and destroying it is safe."""
+    import lpr_381_group_v22_amd as pkg
+    from lpr_381_group_v22_amd import _native as N
+    from lpr_381_group_v22_amd.engine import RevisedState, SensState
+    eng = pkg.Engine(0)
+    tab = pkg.Tableau.synthetic(eng, 24, 40, 1)
+    assert tab.solve().status == 0
+    big = pkg.Tableau.synthetic(eng, 700, 900, 2)      # K-pivot path: owns streams and scratch
+    big.solve(max_pivots=40)
+    rev = RevisedState.synthetic(eng, 16, 24, 0)
+    rev.solve(max_pivots=3)
+    sens = SensState.from_tableau(tab, 40)
+    eng.close()
+    for call in (lambda: tab.solve(), lambda: tab.read(), lambda: tab.basis(),
+                 lambda: tab.pivot_log(), lambda: big.solve(max_pivots=3),
+                 lambda: tab.extract_solution(40), lambda: tab.select_entering(),
+                 lambda: rev.solve(max_pivots=1), lambda: rev.binv(),
+                 lambda: sens.resolve_all()):
+        with pytest.raises(N.EngineError) as ei:
+            call()
+        assert ei.value.status == N.LPR_BAD_ARGUMENT
+    for h in (tab, big, rev, sens):
+        h.destroy()
+        h.destroy()  # idempotent on the Python side
+    eng.close()

@@ -181,3 +181,42 @@ def test_binv_a_zero_skip_is_applied(engine, oracle):
     bound = 1e-9 * (np.abs(Bz) @ np.abs(A)) + 1e-12
     assert (np.abs(got - want) <= bound).all()
     st.destroy()
+
+
+def test_config3_m4096_n8192_iterations_and_product(engine, oracle):
+    """BASELINE configs[2] at full size (m=4096, n=8192): the first iterations against the oracle
+    (about 3 s of one core each) -- status, pivot log, basis, x_B and all of B^-1 bit for bit -- then,
+    after 150 more iterations on the device have filled B^-1 in, the MFMA product B^-1 * A
+    (CaptureSnapshot :360) against the oracle's literal loop on a 64-row slice, with the stated
+    tolerance |err| <= 1e-9 * (|B^-1| |A|)_ij + 1e-12."""
+    from lpr_381_group_v22_amd import RevisedState
+    m, n, seed, iters = 4096, 8192, 0, 3
+    c, A, b = oracle.gen_dense_lp(m, n, seed)
+    ref = oracle.revised_solve(c, A, b, False, max_iter=iters)
+    st = RevisedState.synthetic(engine, m, n, seed)
+    res = st.solve(max_pivots=iters)
+    assert res.status == ref["status"] == 5 and res.iterations == ref["iterations"] == iters
+    assert st.log().tolist() == ref["log"].tolist()
+    assert st.basis().tolist() == ref["basis"].tolist()
+    assert st.xb().tobytes() == ref["xB"].tobytes()
+    assert st.binv().tobytes() == ref["Binv"].tobytes()
+    del ref
+    res = st.solve(max_pivots=150)
+    assert res.iterations == 150
+    Binv = st.binv()
+    got, ms = st.binv_a()
+    assert ms > 0 and got.shape == (m, n)
+    rows = np.r_[0:16, 1000:1016, 2048:2064, 4080:4096]
+    dense = (np.abs(Binv[rows]) >= 1e-9).sum(axis=1)
+    assert dense.max() > 100, "B^-1 rows of the slice are still (almost) unit rows"
+    want = oracle.matmul_skip(Binv[rows], A)
+    bound = 1e-9 * (np.abs(Binv[rows]) @ np.abs(A)) + 1e-12
+    err = np.abs(got[rows] - want)
+    assert (err <= bound).all(), float(err.max())
+    # columns of basic structural variables are unit vectors of B^-1 A (all rows)
+    for row, v in enumerate(st.basis()):
+        if v < n and row % 97 == 0:
+            e = np.zeros(m)
+            e[row] = 1.0
+            assert np.abs(got[:, v] - e).max() < 1e-6
+    st.destroy()

@@ -1,0 +1,39 @@
+# usage: bash tools/r2_run.sh <tag> <step> [<step> ...]   steps: tests-focus | tests-all | probe | bench | profile
+# A step that times out (124/137) or dies on a signal stops the script: no GPU step after a hang.
+set -u
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+mkdir -p gpurun_out
+tag=$1; shift
+run() {  # name, timeout, command...
+    local name=$1 to=$2; shift 2
+    echo "=== $name ($(date +%T))"
+    timeout -k 10 "$to" "$@" > "gpurun_out/${tag}_${name}.log" 2>&1
+    local rc=$?
+    tail -n 15 "gpurun_out/${tag}_${name}.log"
+    echo "=== $name rc=$rc"
+    if [ $rc -eq 124 ] || [ $rc -eq 137 ] || [ $rc -ge 128 ]; then echo "STOP: $name hung or was killed"; exit $rc; fi
+    return 0
+}
+for step in "$@"; do
+  case $step in
+    tests-focus) run tests_focus 900 python -m pytest tests/test_block_gpu.py tests/test_primal_gpu.py tests/test_cut_gpu.py -m gpu -x -q ;;
+    tests-all) run tests_all 1100 python -m pytest tests -m gpu -x -q ;;
+    tests-rest) run tests_rest 1100 python -m pytest tests -m gpu -x -q --deselect tests/test_block_gpu.py --deselect tests/test_primal_gpu.py --deselect tests/test_cut_gpu.py ;;
+    probe) run probe 600 python tools/r2_probe.py ;;
+    probe-quick) run probe 300 python tools/r2_probe.py --quick ;;
+    bench) run bench 600 python bench.py ; run bench_driver 600 python bench.py --gpus 1 --steps 20 --warmup 5 ;;
+    profile)
+      rm -rf gpurun_out/${tag}_kt gpurun_out/${tag}_fetch gpurun_out/${tag}_write
+      run prof_kt 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_kt -o kt -- python3 bench.py --steps 64 --warmup 8 --cpu-pivots 0
+      run prof_fetch 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/${tag}_fetch -o f -- python3 bench.py --steps 24 --warmup 4 --cpu-pivots 0
+      run prof_write 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/${tag}_write -o w -- python3 bench.py --steps 24 --warmup 4 --cpu-pivots 0
+      python tools/pmc_summary.py gpurun_out/${tag}_fetch gpurun_out/${tag}_write k_ov2_sweep 16 4096 8192 > gpurun_out/${tag}_pmc_summary.json
+      find gpurun_out/${tag}_kt -name "*kernel_stats*" -exec cp {} gpurun_out/${tag}_kernel_stats.csv \;
+      # the raw traces are large: keep the summaries only
+      rm -rf gpurun_out/${tag}_fetch gpurun_out/${tag}_write
+      find gpurun_out/${tag}_kt -name "*kernel_trace*" -delete
+      ;;
+    *) echo "unknown step $step"; exit 2 ;;
+  esac
+done
+echo "=== all steps done"
