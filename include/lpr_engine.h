@@ -119,9 +119,12 @@ typedef struct lpr_solve_opts {
                               bits: path + sweep tile (0x30tr two-stream overlap, 0x40tr heads then
                               in-place sweep, 0x50tr one-launch overlap, 0x60tr one launch per head;
                               tr = 0x04/0x08/0x10 rows per chunk, 0x24/0x28 two chunks in flight).
-                              Bits 16..18, K-pivot paths: 0x10000 diagnostic time stamps of the loop
+                              Bits 16..20, K-pivot paths: 0x10000 diagnostic time stamps of the loop
                               heads, 0x20000 loop heads not confined to one XCD, 0x40000 confined
-                              but hand-offs through the memory side. */
+                              but hand-offs through the memory side, 0x80000 the sweep does not
+                              leave the heads' XCD to them, 0x100000 it does so only once this
+                              launch's heads have said where they are (no hint from the previous
+                              launch). */
     int32_t block;         /* pivots decided ahead and applied per sweep of the tableau on large
                               tableaux: 0 auto (16), 1 one pivot per sweep, 2..16 that many.  The bits
                               stored are the same for every value (each element goes through the
@@ -253,6 +256,38 @@ int lpr_revised_xb_read(lpr_revised* s, double* out);
  * This product only feeds the printed tableau, so its contract is a tolerance
  * (|err| <= 1e-9 * sum_k |b_ik a_kj|), not bit equality -- DESIGN.md. */
 int lpr_revised_binv_a(lpr_revised* s, double* out, double* ms);
+
+/* ---- IterationSnapshots of the revised solver (RevisedPrimalSimplexSolver.cs:36, consumed by
+ * Program.cs:329-347).  The C# appends one text block per iteration (CaptureSnapshot :294-387); the
+ * numbers in it come from the device through the three calls below, the host only formats them
+ * (NumFormat.N3 :451-466).  Meant for the models a person reads (snapshot policy "all"); a solve
+ * without snapshots is lpr_revised_solve. */
+typedef struct lpr_revised_snapshot_info {
+    int32_t status;        /* LPR_PIVOT_LIMIT: one pivot done, the loop goes on ("Iteration k"
+                              snapshot, :232-247); LPR_OK_OPTIMAL: the "Optimal" snapshot
+                              (:124-146); any other status: the C# threw, no snapshot */
+    int32_t entering;      /* enteringIdx (-1 on the Optimal snapshot) */
+    int32_t leaving_row;   /* leavingRow, 0-based basis row */
+    int32_t leaving_var;   /* leavingVarIndex_Pre */
+    double entering_rc_pre;  /* :189-191 */
+    double z_working;      /* Dot(cB, xB) :245 / :141 */
+    double z_original;     /* ComputeOriginalZFromCurrentBasis(xB) :246 / finalZ :142 */
+} lpr_revised_snapshot_info;
+
+/* ONE pass of the while-loop of Solve() (:86-249), including the post-pivot recomputation of
+ * x_B, y and the reduced costs (:217-227) that the snapshot prints.  Returns info->status.
+ * Can be mixed freely with lpr_revised_solve on the same handle. */
+int lpr_revised_step(lpr_revised* s, lpr_revised_snapshot_info* info);
+/* What the last lpr_revised_step left: y (m), rc (n + m: rcX then rcS = -y), u_pre (m), ratios_pre
+ * (m, +inf where u_i <= EPS), basisForRatios_Pre (m), x_B (m).  Any pointer may be NULL.  After
+ * an "Optimal" step u / ratios / basis_pre are those of the previous pivot -- the C# prints zeros
+ * and infinities there (:133-134). */
+int lpr_revised_snapshot_read(lpr_revised* s, double* y, double* rc, double* u, double* ratios,
+                              int32_t* basis_pre, double* xB);
+/* MultiplyMatrices(BInverse, A) (:360) in the C#'s own summation order (k ascending, |a_ik| < EPS
+ * skipped, product rounded then added) -- bit-exact, for the printed table of small models, where
+ * a 3-decimal tie must round as the C# rounds it.  out: m x n row-major. */
+int lpr_revised_binv_a_exact(lpr_revised* s, double* out);
 
 /* ------------------------------------------------------- branch and bound */
 

@@ -73,6 +73,18 @@ class RevisedResult(C.Structure):
     ]
 
 
+class RevisedSnapshotInfo(C.Structure):
+    _fields_ = [
+        ("status", C.c_int32),
+        ("entering", C.c_int32),
+        ("leaving_row", C.c_int32),
+        ("leaving_var", C.c_int32),
+        ("entering_rc_pre", C.c_double),
+        ("z_working", C.c_double),
+        ("z_original", C.c_double),
+    ]
+
+
 class BBOpts(C.Structure):
     _fields_ = [
         ("enable_pruning", C.c_int32),
@@ -143,6 +155,9 @@ SIGNATURES = {
     "lpr_revised_binv_read": (C.c_int, [_P, _D]),
     "lpr_revised_xb_read": (C.c_int, [_P, _D]),
     "lpr_revised_binv_a": (C.c_int, [_P, _D, _D]),
+    "lpr_revised_step": (C.c_int, [_P, C.POINTER(RevisedSnapshotInfo)]),
+    "lpr_revised_snapshot_read": (C.c_int, [_P, _D, _D, _D, _D, _I32, _D]),
+    "lpr_revised_binv_a_exact": (C.c_int, [_P, _D]),
     "lpr_bb_create": (C.c_int, [_P, _D, C.c_int, C.c_int, C.c_int, C.c_int, _PP]),
     "lpr_bb_create_from_tableau": (C.c_int, [_P, C.c_int, C.c_int, _PP]),
     "lpr_bb_destroy": (C.c_int, [_P]),

@@ -491,7 +491,17 @@ static int solve_overlapped(lpr_tableau* t, const lpr_solve_opts& o, int K, int 
     int rc = ov_ensure(t, overlap);
     if (rc != LPR_OK_OPTIMAL) return rc;
     const bool timed = o.time_kernels != 0;
-    int nlaunch = o.batch > 0 ? (o.batch + K - 1) / K : (default_batch(t) + K - 1) / K;
+    // steps between host polls: about 5 ms of device work (a step = one sweep at ~5 TB/s, or K loop
+    // heads at ~8 us, whichever is longer); a poll costs the device ~0.1 ms of idling
+    int nlaunch;
+    if (o.batch > 0) {
+        nlaunch = (o.batch + K - 1) / K;
+    } else {
+        const double sweep_us = 16.0 * t->rows * (double)t->ld / 5.0e6;
+        const double step_us = sweep_us > 8.0 * K ? sweep_us : 8.0 * K;
+        nlaunch = (int)(5000.0 / step_us);
+        if (nlaunch > 64) nlaunch = 64;
+    }
     if (nlaunch < 2) nlaunch = 2;
     const int64_t start_iter = t->total_pivots;
     const int64_t max_iter = o.max_pivots > 0 ? start_iter + o.max_pivots : 0;
@@ -844,7 +854,7 @@ int lpr_primal_solve(lpr_tableau* t, const lpr_solve_opts* opts, lpr_solve_resul
     lpr_solve_opts o;
     std::memset(&o, 0, sizeof o);
     if (opts) o = *opts;
-    const int hflags = (o.variant >> 16) & 7;  // loop-head placement / diagnostics (K-pivot paths)
+    const int hflags = (o.variant >> 16) & 31;  // loop-head placement / diagnostics (K-pivot paths)
     o.variant &= 0xffff;                       // path + tile
     lpr_engine* e = t->eng;
     hipStream_t s = e->stream;

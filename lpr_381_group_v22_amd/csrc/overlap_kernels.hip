@@ -46,7 +46,7 @@ struct OvCtl {
     int32_t sweep;     // parity of the sweep direction
     int32_t r[kOvMax]; // pivot rows of that block
     int32_t error;     // a grid barrier timed out
-    int32_t pad;
+    int32_t head_xcc;  // XCD the loop heads of the previous launch shared (-1: none / spread)
     int64_t staged;    // pivots decided so far (index of the next one)
     int64_t applied;   // pivots swept into the tableau so far
     int64_t max_iter;  // <= 0: no limit
@@ -64,6 +64,8 @@ struct OvBuffers {      // everything the step kernel touches, passed by value
     unsigned long long* gran;  // [3][kOvGroups][3] partials as {epoch, 32-bit value} granules:
                                // Z-row partials bank 0 / 1, ratio partials (ov_heads_rich)
     unsigned long long* xgran;  // [kOvGroups] {launch epoch, XCC id} of every head workgroup
+    unsigned long long* hx;     // {launch epoch, 0x100 | XCC id}: the XCD this launch's heads share
+    unsigned* tileq;            // [2] next tile of the sweep (work queue), by launch parity
     unsigned long long* dbg;    // diagnostic time stamps of the lead head workgroup (or null)
     OvCtl* ctl;         // [2]
     unsigned* bar;      // [2]
@@ -85,7 +87,9 @@ __global__ __launch_bounds__(1024) void k_ov_prologue(const double* __restrict__
                                                       unsigned epoch,
                                                       unsigned long long* gran_all,
                                                       unsigned long long* __restrict__ xgran,
-                                                      unsigned* __restrict__ bar) {
+                                                      unsigned* __restrict__ bar,
+                                                      unsigned* __restrict__ tileq,
+                                                      unsigned long long* __restrict__ hx) {
     __shared__ double lds_v[16];
     __shared__ int lds_i[16];
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -93,6 +97,8 @@ __global__ __launch_bounds__(1024) void k_ov_prologue(const double* __restrict__
     for (int k = tid; k < 9 * kOvGroups; k += nt) gran_all[k] = 0ull;
     for (int k = tid; k < kOvGroups; k += nt) xgran[k] = 0ull;
     if (tid < 4) bar[tid] = 0u;
+    if (tid < 2) tileq[tid] = 0u;
+    if (tid == 0) *hx = 0ull;
     __syncthreads();
     Cand c;
     c.v = 0.0;
@@ -509,6 +515,7 @@ __device__ void ov_heads(const OvBuffers B, int ld, int R, int C, int Rp, int K,
         co->max_iter = mx;
         co->log_cap = log_cap;
         co->error = err | ci->error;
+        co->head_xcc = -1;
         B.bar[lp ^ 1] = 0u;  // nobody touches the other counter during this launch
         if (solo) {  // no sweep in this launch: its fields are carried over here
             co->applied = ci->applied;
@@ -694,6 +701,10 @@ __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, i
             l2 = s_pick[0] != 0;
             if (s_pick[1]) err = 1;
             __syncthreads();
+            // tell the sweep running beside this launch which XCD to leave to the heads
+            if (lead && tid == 0 && l2 && !solo)
+                __hip_atomic_store(B.hx, ((unsigned long long)xepoch << 32) | 0x100u | my_xcc,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (STAMP && stamp) {
                 B.dbg[(size_t)kOvStampPivots * kOvStampsPerPivot + 0] = my_xcc;
                 B.dbg[(size_t)kOvStampPivots * kOvStampsPerPivot + 1] = l2 ? 1u : 0u;
@@ -1026,8 +1037,10 @@ __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, i
         co->max_iter = mx;
         co->log_cap = log_cap;
         co->error = err | ci->error;
+        co->head_xcc = l2 ? (int)my_xcc : (staging ? -1 : ci->head_xcc);
         B.bar[lp ^ 1] = 0u;
         if (solo) {
+            B.tileq[1] = 0u;  // the in-place sweep that follows always runs on control block 1
             co->applied = ci->applied;
             co->cur = ci->cur;
             co->sweep = ci->sweep;
@@ -1111,34 +1124,23 @@ __device__ __forceinline__ void ov_rows_store(const ov_v2d (&x)[TR], ov_v2d* dst
 
 // TR rows per chunk; DB: the next chunk's rows are requested before the current chunk is computed
 // (two register sets), so a wave always has loads in flight.
+//
+// Work distribution: the launch is PERSISTENT (a few workgroups per CU); every workgroup takes the
+// next tile from a counter in memory until none is left.  Workgroups are dealt to the 8 XCDs round
+// robin, so with a static tile -> workgroup map the slowest XCD sets the time of the sweep -- and
+// one XCD is slow by design: the one that hosts the loop heads of the next block (ov_heads_rich),
+// which run beside this sweep with a high priority and one wave per SIMD.  With the queue every XCD
+// takes what it can, and the heads' XCD takes nothing: its workgroups leave at once when the
+// previous launch's heads sat there (the hint `head_xcc` of the control block), or as soon as this
+// launch's heads have said where they are (B.hx) -- the heads then run as fast as with nothing
+// beside them.  Wrong or missing hints cost time, never correctness: any workgroup may take any
+// tile.  `static_tile` >= 0: one given tile (the one-launch form k_ov_step has no queue).
 template <int TR, bool DB, bool INPLACE>
-__device__ __forceinline__ void ov_tiles(const OvBuffers& B, const double* __restrict__ fcol,
-                                         const double* __restrict__ prow, int ld, int R, int Rp,
-                                         int G, int lp) {
+__device__ __forceinline__ void ov_one_tile(const OvBuffers& B, const OvCtl* ci,
+                                            const double* __restrict__ fc,
+                                            const ov_v2d* __restrict__ prow2, int tb, int ld,
+                                            int R, int Rp, int K, int cur) {
     typedef ov_v2d v2d;
-    static_assert(kOvTileRows % (2 * TR) == 0, "tile rows must be a multiple of two chunks");
-    const OvCtl* ci = B.ctl + lp;
-    const int tb = blockIdx.x - G;
-    const int K = (ci->status == kRunning) ? ci->kdone : 0;
-    const int cur = ci->cur;
-    if (tb == 0 && threadIdx.x == 0) {  // the next launch's view (fields owned by the sweep)
-        OvCtl* co = B.ctl + (lp ^ 1);
-        co->applied = ci->applied + K;
-        co->cur = (K > 0 && !INPLACE) ? (cur ^ 1) : cur;
-        co->sweep = ci->sweep ^ 1;
-        if (INPLACE) {  // no heads in this launch: their fields are carried over here
-            co->status = ci->status;
-            co->pending = ci->pending;
-            co->kdone = 0;
-            co->slot = ci->slot;
-            co->staged = ci->staged;
-            co->max_iter = ci->max_iter;
-            co->log_cap = ci->log_cap;
-            co->error = ci->error;
-            B.bar[lp ^ 1] = 0u;
-        }
-    }
-    if (K <= 0) return;
     const int ld2 = ld >> 1;
     const int nct = (ld2 + kOvNT - 1) / kOvNT;
     const int nrt = (R + kOvTileRows - 1) / kOvTileRows;
@@ -1150,9 +1152,6 @@ __device__ __forceinline__ void ov_tiles(const OvBuffers& B, const double* __res
     }
     const int c2 = ct * kOvNT + threadIdx.x;
     if (c2 >= ld2) return;
-    const int sa = ci->slot;
-    const double* __restrict__ fc = fcol + (size_t)sa * kOvMax * Rp;
-    const v2d* __restrict__ prow2 = reinterpret_cast<const v2d*>(prow + (size_t)sa * kOvMax * ld);
     // in place every element is read and written by the same lane; out of place the buffers differ
     const v2d* Tin2 = reinterpret_cast<const v2d*>(B.Tb[cur]);
     v2d* Tout2 = reinterpret_cast<v2d*>(B.Tb[INPLACE ? cur : (cur ^ 1)]);
@@ -1266,6 +1265,75 @@ __device__ __forceinline__ void ov_tiles(const OvBuffers& B, const double* __res
     }
 }
 
+// avoid: 0 = never leave an XCD to the heads, 1 = live word only (B.hx), 2 = hint + live word
+template <int TR, bool DB, bool INPLACE>
+__device__ __forceinline__ void ov_tiles(const OvBuffers& B, const double* __restrict__ fcol,
+                                         const double* __restrict__ prow, int ld, int R, int Rp,
+                                         int G, int lp, int static_tile, int avoid) {
+    static_assert(kOvTileRows % (2 * TR) == 0, "tile rows must be a multiple of two chunks");
+    __shared__ int s_tile;
+    const OvCtl* ci = B.ctl + lp;
+    const int K = (ci->status == kRunning) ? ci->kdone : 0;
+    const int cur = ci->cur;
+    const bool first_wg = ((int)blockIdx.x == G);
+    if (first_wg && threadIdx.x == 0) {  // the next launch's view (fields owned by the sweep)
+        OvCtl* co = B.ctl + (lp ^ 1);
+        co->applied = ci->applied + K;
+        co->cur = (K > 0 && !INPLACE) ? (cur ^ 1) : cur;
+        co->sweep = ci->sweep ^ 1;
+        B.tileq[lp ^ 1] = 0u;  // nobody touches the other queue during this launch
+        if (INPLACE) {  // no heads in this launch: their fields are carried over here
+            co->status = ci->status;
+            co->pending = ci->pending;
+            co->kdone = 0;
+            co->slot = ci->slot;
+            co->staged = ci->staged;
+            co->max_iter = ci->max_iter;
+            co->log_cap = ci->log_cap;
+            co->error = ci->error;
+            co->head_xcc = ci->head_xcc;
+            B.bar[lp ^ 1] = 0u;
+        }
+    }
+    if (K <= 0) return;
+    const int sa = ci->slot;
+    const double* __restrict__ fc = fcol + (size_t)sa * kOvMax * Rp;
+    const ov_v2d* __restrict__ prow2 =
+        reinterpret_cast<const ov_v2d*>(prow + (size_t)sa * kOvMax * ld);
+    if (static_tile >= 0) {
+        ov_one_tile<TR, DB, INPLACE>(B, ci, fc, prow2, static_tile, ld, R, Rp, K, cur);
+        return;
+    }
+    const int ld2 = ld >> 1;
+    const int ntiles = ((ld2 + kOvNT - 1) / kOvNT) * ((R + kOvTileRows - 1) / kOvTileRows);
+    // do loop heads that stage a block run beside this launch, and where?
+    const bool heads_beside = !INPLACE && avoid > 0 && ci->status == kRunning &&
+                              ci->pending == kRunning;
+    const unsigned my_xcc = ov_xcc_id();
+    if (heads_beside && avoid > 1 && ci->head_xcc == (int)my_xcc) return;
+    const unsigned xepoch = (unsigned)(ci->staged + 1);
+    for (;;) {
+        if (threadIdx.x == 0) {
+            int tile = -1;
+            if (heads_beside) {
+                const unsigned long long v =
+                    __hip_atomic_load(B.hx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)(v >> 32) == xepoch && ((unsigned)v & 0x1ffu) == (0x100u | my_xcc))
+                    tile = ntiles;  // this launch's heads share this XCD: leave it to them
+            }
+            if (tile < 0)
+                tile = (int)__hip_atomic_fetch_add(B.tileq + lp, 1u, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
+            s_tile = tile;
+        }
+        __syncthreads();
+        const int tile = s_tile;
+        __syncthreads();
+        if (tile >= ntiles) return;
+        ov_one_tile<TR, DB, INPLACE>(B, ci, fc, prow2, tile, ld, R, Rp, K, cur);
+    }
+}
+
 template <int TR, bool DB>
 __global__ __launch_bounds__(kOvNT) void k_ov_step(const OvBuffers B,
                                                    const double* __restrict__ fcol_ro,
@@ -1276,7 +1344,7 @@ __global__ __launch_bounds__(kOvNT) void k_ov_step(const OvBuffers B,
     if ((int)blockIdx.x < G)
         ov_heads<kOvNT>(B, ld, R, C, Rp, K, G, lp, false);
     else
-        ov_tiles<TR, DB, false>(B, fcol_ro, prow_ro, ld, R, Rp, G, lp);
+        ov_tiles<TR, DB, false>(B, fcol_ro, prow_ro, ld, R, Rp, G, lp, (int)blockIdx.x - G, 0);
 }
 
 // The two halves as separate kernels on two streams, running concurrently (variant 0x30tr): same
@@ -1292,8 +1360,8 @@ template <int TR, bool DB>
 __global__ __launch_bounds__(kOvNT) void k_ov2_sweep(const OvBuffers B,
                                                      const double* __restrict__ fcol_ro,
                                                      const double* __restrict__ prow_ro, int ld,
-                                                     int R, int Rp, int lp) {
-    ov_tiles<TR, DB, false>(B, fcol_ro, prow_ro, ld, R, Rp, 0, lp);
+                                                     int R, int Rp, int lp, int avoid) {
+    ov_tiles<TR, DB, false>(B, fcol_ro, prow_ro, ld, R, Rp, 0, lp, -1, avoid);
 }
 
 // The same two halves as separate launches: all K loop heads of a block in ONE persistent launch
@@ -1310,7 +1378,7 @@ __global__ __launch_bounds__(kOvNT) void k_ov_sweep(const OvBuffers B,
                                                     const double* __restrict__ fcol_ro,
                                                     const double* __restrict__ prow_ro, int ld,
                                                     int R, int Rp) {
-    ov_tiles<TR, DB, true>(B, fcol_ro, prow_ro, ld, R, Rp, 0, 1);
+    ov_tiles<TR, DB, true>(B, fcol_ro, prow_ro, ld, R, Rp, 0, 1, -1, 0);
 }
 
 }  // namespace lpr
@@ -1359,6 +1427,8 @@ void ov_release(lpr_tableau* t) {
     hipFree(c->b.rparts);
     hipFree(c->b.gran);
     hipFree(c->b.xgran);
+    hipFree(c->b.hx);
+    hipFree(c->b.tileq);
     hipFree(c->b.dbg);
     hipFree(c->b.ctl);
     hipFree(c->b.bar);
@@ -1392,6 +1462,8 @@ int ov_ensure(lpr_tableau* t, bool second_buffer) {
     chk(hipMalloc(&c->b.gran, (size_t)9 * kOvGroups * sizeof(unsigned long long)));
     chk(hipMalloc(&c->b.xgran, (size_t)kOvGroups * sizeof(unsigned long long)));
     chk(hipMalloc(&c->b.dbg, kOvDbgWords * sizeof(unsigned long long)));
+    chk(hipMalloc(&c->b.hx, 2 * sizeof(unsigned long long)));
+    chk(hipMalloc(&c->b.tileq, 4 * sizeof(unsigned)));
     chk(hipMalloc(&c->b.ctl, 2 * sizeof(OvCtl)));
     chk(hipMalloc(&c->b.bar, 4 * sizeof(unsigned)));
     chk(hipHostMalloc(&c->h_ctl, 2 * sizeof(OvCtl)));
@@ -1422,6 +1494,17 @@ static int ov_tile_code(int tr) {
     }
 }
 
+// One XCD has 32 CUs and a head workgroup needs a CU of its own (its lanes keep their slices of the
+// block in registers: one wave per SIMD): more than 32 groups cannot be resident on one XCD
+// together, and a group that is not resident never answers a hand-off.  Wider tableaux spread.
+static int ov_spread(int G, int flags) { return ((flags & 2) || G > 32) ? 1 : 8; }
+
+// persistent sweep: enough workgroups to fill every CU at the kernel's occupancy (4 per CU)
+static int ov_sweep_grid(const lpr_tableau* t, int ntiles) {
+    const int cap = 4 * (t->eng->num_cus > 0 ? t->eng->num_cus : 256);
+    return ntiles < cap ? (ntiles > 0 ? ntiles : 1) : cap;
+}
+
 static int ov_groups(const lpr_tableau* t) {
     int g = (t->ld / 2 + kOvNT - 1) / kOvNT;
     if (g < 1) g = 1;
@@ -1445,13 +1528,14 @@ int ov_begin(lpr_tableau* t, int64_t iter, int64_t max_iter) {
     h[0].applied = iter;
     h[0].max_iter = max_iter;
     h[0].log_cap = t->log_cap;
+    h[0].head_xcc = -1;
     h[1] = h[0];
     LPR_HIP(hipMemcpyAsync(c->b.ctl, h, 2 * sizeof(OvCtl), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_ov_prologue, dim3(1), dim3(1024), 0, s, t->T, t->ld, t->rows, t->cols,
                        c->b.zrow, c->b.bvec + (size_t)(iter & 1) * c->Rp,
                        c->b.zparts + (iter & 1) * kOvGroups, ov_groups(t),
                        c->b.gran + (size_t)(iter & 1) * 3 * kOvGroups, (unsigned)(2 * iter + 1),
-                       c->b.gran, c->b.xgran, c->b.bar);
+                       c->b.gran, c->b.xgran, c->b.bar, c->b.tileq, c->b.hx);
     LPR_HIP(hipGetLastError());
     return LPR_OK_OPTIMAL;
 }
@@ -1489,7 +1573,7 @@ void ov_launch_step(lpr_tableau* t, int K, int tr, int lp) {
 void ov_launch_heads(lpr_tableau* t, int K, int flags) {
     lpr_overlap_ctx* c = static_cast<lpr_overlap_ctx*>(t->ov);
     const int G = ov_groups(t);  // 256 lanes per group; 512 measures the same, 1024 slower
-    const int spread = (flags & 2) ? 1 : 8;
+    const int spread = ov_spread(G, flags);
     const int no_l2 = (flags & 6) ? 1 : 0;
     hipStream_t s = t->eng->stream;
     if (flags & 1)
@@ -1505,7 +1589,7 @@ void ov_launch_sweep(lpr_tableau* t, int tr) {
     hipStream_t s = t->eng->stream;
     const int nct = (t->ld / 2 + kOvNT - 1) / kOvNT;
     const int nrt = (t->rows + kOvTileRows - 1) / kOvTileRows;
-    const dim3 grid(nct * nrt), blk(kOvNT);
+    const dim3 grid(ov_sweep_grid(t, nct * nrt)), blk(kOvNT);
 #define LPR_OV_SWEEP(TR, DB)                                                                     \
     hipLaunchKernelGGL((k_ov_sweep<TR, DB>), grid, blk, 0, s, c->b, c->b.fcol, c->b.prow, t->ld,  \
                        t->rows, c->Rp)
@@ -1548,7 +1632,7 @@ int ov2_launch_step(lpr_tableau* t, int K, int tr, int lp, int flags, hipEvent_t
     LPR_HIP(hipStreamWaitEvent(S, c->ev_h[prev], 0));
     if (ev_start) LPR_HIP(hipEventRecord(ev_start, S));  // both kernels of the previous step done
     const int G = ov_groups(t);
-    const int spread = (flags & 2) ? 1 : 8;
+    const int spread = ov_spread(G, flags);
     const int no_l2 = (flags & 6) ? 1 : 0;
     if (flags & 1)
         hipLaunchKernelGGL((k_ov2_heads<kOvNT, true>), dim3(G * spread), dim3(kOvNT), 0, H, c->b,
@@ -1559,10 +1643,14 @@ int ov2_launch_step(lpr_tableau* t, int K, int tr, int lp, int flags, hipEvent_t
     LPR_HIP(hipEventRecord(c->ev_h[cur], H));
     const int nct = (t->ld / 2 + kOvNT - 1) / kOvNT;
     const int nrt = (t->rows + kOvTileRows - 1) / kOvTileRows;
-    const dim3 grid(nct * nrt), blk(kOvNT);
+    const dim3 grid(ov_sweep_grid(t, nct * nrt)), blk(kOvNT);
+    // leave the heads' XCD to the heads: 2 = by the previous launch's hint and this launch's
+    // word, 1 = by this launch's word only, 0 = never (flags 8 / 16; nothing to leave when the
+    // heads are not confined to one XCD)
+    const int avoid = (flags & (2 | 4 | 8)) ? 0 : ((flags & 16) ? 1 : 2);
 #define LPR_OV2_SWEEP(TR, DB)                                                                    \
     hipLaunchKernelGGL((k_ov2_sweep<TR, DB>), grid, blk, 0, S, c->b, c->b.fcol, c->b.prow, t->ld, \
-                       t->rows, c->Rp, lp)
+                       t->rows, c->Rp, lp, avoid)
     switch (ov_tile_code(tr)) {
         case 0x04: LPR_OV2_SWEEP(4, false); break;
         case 0x10: LPR_OV2_SWEEP(16, false); break;

@@ -48,6 +48,11 @@ struct lpr_revised {
     lpr::RevState* h_state = nullptr;  // pinned
     double* gemm_out = nullptr;  // m x ldc scratch of lpr_revised_binv_a (lazy)
     int ldc = 0;
+    // what CaptureSnapshot (:294-387) prints besides y / rc / xB / B^-1 (lazy, lpr_revised_step)
+    double* snap_ratios = nullptr;   // m   ratios_pre (:161,:174), +inf where u_i <= EPS
+    int32_t* snap_basis = nullptr;   // m   basisForRatios_Pre (:186)
+    double* snap_scal = nullptr;     // [0] enteringRC_pre (:189-191), [1] zWorking = Dot(cB, xB)
+    double* h_snap_scal = nullptr;   // pinned, 4 doubles: + [2] zOriginal
     int64_t total_iter = 0;
     int last_status = 0;
 };

@@ -11,7 +11,10 @@
 namespace lpr {
 
 // revised_kernels.hip
-void rev_launch_iteration(lpr_revised* s);
+void rev_launch_iteration(lpr_revised* s, bool snapshot);
+void rev_launch_prices(lpr_revised* s);
+void rev_launch_zworking(lpr_revised* s);
+void rev_launch_matmul_exact(lpr_revised* s, double* Cout, int ldc);
 void rev_launch_extract(lpr_revised* s);
 void rev_launch_init(lpr_revised* s);
 void rev_launch_synthetic(lpr_revised* s, uint64_t seed);
@@ -25,6 +28,10 @@ static void rev_release_device(lpr_revised* s) {
     hipFree(s->u); hipFree(s->fac); hipFree(s->browbuf); hipFree(s->x); hipFree(s->z);
     hipFree(s->basic); hipFree(s->is_basic); hipFree(s->log); hipFree(s->state);
     hipFree(s->gemm_out);
+    hipFree(s->snap_ratios); hipFree(s->snap_basis); hipFree(s->snap_scal);
+    if (s->h_snap_scal) hipHostFree(s->h_snap_scal);
+    s->snap_ratios = s->snap_scal = s->h_snap_scal = nullptr;
+    s->snap_basis = nullptr;
     if (s->h_state) hipHostFree(s->h_state);
     s->A = s->Binv = s->b = s->c = s->cOrig = s->cB = s->xB = s->y = s->rcx = s->acol = nullptr;
     s->u = s->fac = s->browbuf = s->x = s->z = s->gemm_out = nullptr;
@@ -225,7 +232,7 @@ int lpr_revised_solve(lpr_revised* s, const lpr_solve_opts* opts, lpr_revised_re
             LPR_HIP(hipMemcpyAsync(&s->state->log_cap, &hs->log_cap, sizeof(int64_t),
                                    hipMemcpyHostToDevice, st));
         }
-        for (int k = 0; k < batch; ++k) rev_launch_iteration(s);
+        for (int k = 0; k < batch; ++k) rev_launch_iteration(s, false);
         LPR_HIP(hipGetLastError());
         LPR_HIP(hipMemcpyAsync(hs, s->state, sizeof(RevState), hipMemcpyDeviceToHost, st));
         LPR_HIP(hipStreamSynchronize(st));
@@ -251,6 +258,135 @@ int lpr_revised_solve(lpr_revised* s, const lpr_solve_opts* opts, lpr_revised_re
         LPR_HIP(hipStreamSynchronize(st));
     }
     return status;
+}
+
+static int rev_ensure_snap(lpr_revised* s) {
+    if (s->snap_ratios) return LPR_OK_OPTIMAL;
+    LPR_HIP(hipMalloc(&s->snap_ratios, (size_t)s->ldb * sizeof(double)));
+    LPR_HIP(hipMalloc(&s->snap_basis, (size_t)s->m * sizeof(int32_t)));
+    LPR_HIP(hipMalloc(&s->snap_scal, 4 * sizeof(double)));
+    LPR_HIP(hipHostMalloc(&s->h_snap_scal, 4 * sizeof(double)));
+    LPR_HIP(hipMemsetAsync(s->snap_scal, 0, 4 * sizeof(double), s->eng->stream));
+    return LPR_OK_OPTIMAL;
+}
+
+int lpr_revised_step(lpr_revised* s, lpr_revised_snapshot_info* info) {
+    LPR_LIVE_REV(s);
+    if (!info) return LPR_BAD_ARGUMENT;
+    hipStream_t st = s->eng->stream;
+    LPR_HIP(hipSetDevice(s->eng->device));
+    int rc = rev_ensure_snap(s);
+    if (rc != LPR_OK_OPTIMAL) return rc;
+    rc = rev_ensure_log(s, s->total_iter + 2);
+    if (rc != LPR_OK_OPTIMAL) return rc;
+    RevState* hs = s->h_state;
+    hs->status = kRunning;
+    hs->entering = -1;
+    hs->leaving_row = -1;
+    hs->iter = s->total_iter;
+    hs->max_iter = 0;
+    hs->log_cap = s->log_cap;
+    LPR_HIP(hipMemcpyAsync(s->state, hs, sizeof(RevState), hipMemcpyHostToDevice, st));
+    rev_launch_iteration(s, true);
+    LPR_HIP(hipGetLastError());
+    LPR_HIP(hipMemcpyAsync(hs, s->state, sizeof(RevState), hipMemcpyDeviceToHost, st));
+    LPR_HIP(hipStreamSynchronize(st));
+    std::memset(info, 0, sizeof *info);
+    info->entering = hs->entering;
+    info->leaving_row = -1;
+    info->leaving_var = -1;
+    int status = hs->status;
+    if (status == kRunning) {  // a pivot was made: the post-pivot quantities of :217-247
+        if (hs->iter != s->total_iter + 1) {
+            set_error("revised simplex step made no progress (device status still running)");
+            return LPR_DEVICE_ERROR;
+        }
+        int32_t trip[3] = {-1, -1, -1};
+        LPR_HIP(hipMemcpyAsync(trip, s->log + 3 * s->total_iter, sizeof trip,
+                               hipMemcpyDeviceToHost, st));
+        s->total_iter += 1;
+        rev_launch_prices(s);     // xB, y_post, rc_post (status is still "running")
+        rev_launch_extract(s);    // ComputeOriginalZFromCurrentBasis(xB) (:246, :253-262)
+        rev_launch_zworking(s);   // Dot(cB, xB) (:245)
+        LPR_HIP(hipGetLastError());
+        LPR_HIP(hipMemcpyAsync(s->h_snap_scal, s->snap_scal, 2 * sizeof(double),
+                               hipMemcpyDeviceToHost, st));
+        LPR_HIP(hipMemcpyAsync(s->h_snap_scal + 2, s->z, sizeof(double), hipMemcpyDeviceToHost,
+                               st));
+        LPR_HIP(hipStreamSynchronize(st));
+        info->leaving_row = trip[0];
+        info->leaving_var = trip[2];
+        info->entering_rc_pre = s->h_snap_scal[0];
+        info->z_working = s->h_snap_scal[1];
+        info->z_original = s->h_snap_scal[2];
+        status = LPR_PIVOT_LIMIT;  // "one pivot done, not finished"
+    } else if (status == LPR_OK_OPTIMAL) {  // the "Optimal" snapshot of :124-146
+        rev_launch_extract(s);              // ExtractSolution (:126): SolutionVector, finalZ
+        rev_launch_zworking(s);
+        LPR_HIP(hipGetLastError());
+        LPR_HIP(hipMemcpyAsync(s->h_snap_scal + 1, s->snap_scal + 1, sizeof(double),
+                               hipMemcpyDeviceToHost, st));
+        LPR_HIP(hipMemcpyAsync(s->h_snap_scal + 2, s->z, sizeof(double), hipMemcpyDeviceToHost,
+                               st));
+        LPR_HIP(hipStreamSynchronize(st));
+        info->z_working = s->h_snap_scal[1];
+        info->z_original = s->h_snap_scal[2];
+    } else if (status == LPR_PIVOT_TOO_SMALL) {
+        // the C# has done the bookkeeping of :194-212 before UpdateBInverse throws (:267)
+        s->total_iter = hs->iter;
+    }
+    s->last_status = status == LPR_PIVOT_LIMIT ? (int)kRunning : status;
+    info->status = status;
+    return status;
+}
+
+int lpr_revised_snapshot_read(lpr_revised* s, double* y, double* rc, double* u, double* ratios,
+                              int32_t* basis_pre, double* xB) {
+    LPR_LIVE_REV(s);
+    hipStream_t st = s->eng->stream;
+    LPR_HIP(hipSetDevice(s->eng->device));
+    const size_t D = sizeof(double);
+    if ((ratios || basis_pre) && !s->snap_ratios) {
+        set_error("lpr_revised_snapshot_read: no lpr_revised_step has run on this handle");
+        return LPR_BAD_ARGUMENT;
+    }
+    std::vector<double> yy;
+    if (rc) yy.resize((size_t)s->m);
+    if (y) LPR_HIP(hipMemcpyAsync(y, s->y, (size_t)s->m * D, hipMemcpyDeviceToHost, st));
+    if (rc) {
+        LPR_HIP(hipMemcpyAsync(rc, s->rcx, (size_t)s->n * D, hipMemcpyDeviceToHost, st));
+        LPR_HIP(hipMemcpyAsync(yy.data(), s->y, (size_t)s->m * D, hipMemcpyDeviceToHost, st));
+    }
+    if (u) LPR_HIP(hipMemcpyAsync(u, s->u, (size_t)s->m * D, hipMemcpyDeviceToHost, st));
+    if (ratios)
+        LPR_HIP(hipMemcpyAsync(ratios, s->snap_ratios, (size_t)s->m * D, hipMemcpyDeviceToHost,
+                               st));
+    if (basis_pre)
+        LPR_HIP(hipMemcpyAsync(basis_pre, s->snap_basis, (size_t)s->m * sizeof(int32_t),
+                               hipMemcpyDeviceToHost, st));
+    if (xB) LPR_HIP(hipMemcpyAsync(xB, s->xB, (size_t)s->m * D, hipMemcpyDeviceToHost, st));
+    LPR_HIP(hipStreamSynchronize(st));
+    if (rc)  // rcS_k = -y_k (:100-102, :225-227): a sign flip, exact
+        for (int k = 0; k < s->m; ++k) rc[s->n + k] = -yy[(size_t)k];
+    return LPR_OK_OPTIMAL;
+}
+
+int lpr_revised_binv_a_exact(lpr_revised* s, double* out) {
+    LPR_LIVE_REV(s);
+    if (!out) return LPR_BAD_ARGUMENT;
+    hipStream_t st = s->eng->stream;
+    LPR_HIP(hipSetDevice(s->eng->device));
+    if (!s->gemm_out) {
+        s->ldc = align_up(s->n, kLdAlign);
+        LPR_HIP(hipMalloc(&s->gemm_out, (size_t)s->m * s->ldc * sizeof(double)));
+    }
+    rev_launch_matmul_exact(s, s->gemm_out, s->ldc);
+    LPR_HIP(hipGetLastError());
+    LPR_HIP(hipMemcpy2DAsync(out, (size_t)s->n * sizeof(double), s->gemm_out,
+                             (size_t)s->ldc * sizeof(double), (size_t)s->n * sizeof(double), s->m,
+                             hipMemcpyDeviceToHost, st));
+    LPR_HIP(hipStreamSynchronize(st));
+    return LPR_OK_OPTIMAL;
 }
 
 int lpr_revised_solution(lpr_revised* s, double* x, double* z) {

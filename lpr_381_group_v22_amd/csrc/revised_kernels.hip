@@ -512,6 +512,64 @@ __global__ __launch_bounds__(256) void k_rev_extract(const int32_t* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------
+// What CaptureSnapshot (:294-387) shows of the PRE-pivot state, kept before k_rev_ratio changes the
+// basis: ratios_pre[i] = xB_i / u_i where u_i > EPS, else +inf (:159-175); the pre-pivot basis
+// (:186); the entering variable's reduced cost (:189-191).
+__global__ __launch_bounds__(256) void k_rev_snap_pre(const double* __restrict__ u,
+                                                      const double* __restrict__ xB,
+                                                      const int32_t* __restrict__ basic,
+                                                      const double* __restrict__ rcx,
+                                                      const double* __restrict__ y, int n, int m,
+                                                      double* __restrict__ ratios,
+                                                      int32_t* __restrict__ basis_pre,
+                                                      double* __restrict__ scal,
+                                                      const RevState* __restrict__ st) {
+    if (st->status != kRunning) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) {
+        const int e = st->entering;
+        scal[0] = (e < n) ? rcx[e] : -y[e - n];
+    }
+    if (i >= m) return;
+    const double ui = u[i];
+    ratios[i] = (ui > kEps) ? xB[i] / ui : (double)INFINITY;
+    basis_pre[i] = basic[i];
+}
+
+// zWorking = Dot(cB, xB) (:245, :141): a sequential sum, one lane.
+__global__ void k_rev_dot(const double* __restrict__ a, const double* __restrict__ b, int len,
+                          double* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double s = 0.0;
+    for (int i = 0; i < len; ++i) {
+        const double p = a[i] * b[i];
+        s = s + p;
+    }
+    *out = s;
+}
+
+// MultiplyMatrices(BInverse, A) (:360, :426-441) in the C#'s own order, for the PRINTED table of
+// small models: R[i,j] starts at +0.0 and receives aik * B[k,j] for k ascending, skipping
+// |aik| < EPS; product rounded, then the add.  One lane per output element.  (The MFMA product
+// k_rev_gemm associates differently; at 3 printed decimals that can flip a digit on a tie.)
+__global__ __launch_bounds__(256) void k_rev_matmul_exact(const double* __restrict__ Binv, int ldb,
+                                                          const double* __restrict__ A, int lda,
+                                                          double* __restrict__ C, int ldc, int m,
+                                                          int n) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= n || i >= m) return;
+    double s = 0.0;
+    for (int k = 0; k < m; ++k) {
+        const double aik = Binv[(size_t)i * ldb + k];
+        if (fabs(aik) < kEps) continue;
+        const double p = aik * A[(size_t)k * lda + j];
+        s = s + p;
+    }
+    C[(size_t)i * ldc + j] = s;
+}
+
+// ------------------------------------------------------------------------------------------
 // Synthetic dense LP for the benchmark (same generator as the tableau form).
 __device__ __forceinline__ uint64_t rsplitmix64(uint64_t x) {
     x += 0x9E3779B97F4A7C15ULL;
@@ -707,7 +765,9 @@ __global__ __launch_bounds__(256, 2) void k_rev_gemm(const double* __restrict__ 
 // ------------------------------------------------------------------------------------------
 // launchers
 
-void rev_launch_iteration(lpr_revised* s) {
+// x_B = B^-1 b, y = c_B B^-1, rc_j = c_j - y.A_j: the head of an iteration (:89-102) and, with the
+// same operands after the pivot, the post-pivot quantities of the snapshot (:217-227).
+void rev_launch_prices(lpr_revised* s) {
     hipStream_t st = s->eng->stream;
     const int m = s->m, n = s->n;
     // x_B = B^-1 b (:89)
@@ -719,6 +779,24 @@ void rev_launch_iteration(lpr_revised* s) {
     // rc_j = c_j - y.A_j (:96-98)
     hipLaunchKernelGGL(k_rev_colsum, dim3((n + kCB - 1) / kCB), dim3(256), 0, st, s->A, s->lda, m,
                        n, s->y, s->c, s->rcx, 1, s->state);
+}
+
+void rev_launch_zworking(lpr_revised* s) {
+    hipLaunchKernelGGL(k_rev_dot, dim3(1), dim3(64), 0, s->eng->stream, s->cB, s->xB, s->m,
+                       s->snap_scal + 1);
+}
+
+void rev_launch_matmul_exact(lpr_revised* s, double* Cout, int ldc) {
+    hipLaunchKernelGGL(k_rev_matmul_exact, dim3((s->n + 255) / 256, s->m), dim3(256), 0,
+                       s->eng->stream, s->Binv, s->ldb, s->A, s->lda, Cout, ldc, s->m, s->n);
+}
+
+// One iteration of Solve() (:86-249).  `snapshot`: also keep the pre-pivot ratios / basis /
+// entering reduced cost for CaptureSnapshot (s->snap_* must exist).
+void rev_launch_iteration(lpr_revised* s, bool snapshot) {
+    hipStream_t st = s->eng->stream;
+    const int m = s->m, n = s->n;
+    rev_launch_prices(s);
     hipLaunchKernelGGL(k_rev_enter, dim3(1), dim3(1024), 0, st, s->rcx, s->y, s->xB, s->is_basic,
                        n, m, s->state);
     hipLaunchKernelGGL(k_rev_gather, dim3((m + 255) / 256), dim3(256), 0, st, s->A, s->lda,
@@ -726,6 +804,10 @@ void rev_launch_iteration(lpr_revised* s) {
     // u = B^-1 a_e (:150) unless the entering variable is a slack
     hipLaunchKernelGGL(k_rev_rowsum, dim3((m + kRB - 1) / kRB), dim3(256), 0, st, s->Binv, s->ldb,
                        m, s->acol, s->u, s->state, 1, n);
+    if (snapshot)
+        hipLaunchKernelGGL(k_rev_snap_pre, dim3((m + 255) / 256), dim3(256), 0, st, s->u, s->xB,
+                           s->basic, s->rcx, s->y, n, m, s->snap_ratios, s->snap_basis,
+                           s->snap_scal, s->state);
     hipLaunchKernelGGL(k_rev_ratio, dim3(1), dim3(1024), 0, st, s->u, s->xB, s->basic,
                        s->is_basic, s->cB, s->c, s->Binv, s->ldb, s->browbuf, s->fac, s->log, n, m,
                        s->state);

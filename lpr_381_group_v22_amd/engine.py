@@ -320,6 +320,32 @@ class RevisedState:
         return out, ms.value
 
 
+    # ---- IterationSnapshots (RevisedPrimalSimplexSolver.cs:294-387) -----------------------
+    def step(self) -> N.RevisedSnapshotInfo:
+        """One pass of Solve()'s loop incl. the post-pivot quantities (lpr_revised_step)."""
+        info = N.RevisedSnapshotInfo()
+        N.check(N.lib.lpr_revised_step(self._h, C.byref(info)), "lpr_revised_step")
+        return info
+
+    def snapshot(self):
+        """(y, rc[n+m], u_pre, ratios_pre, basis_pre, xB) as left by the last step()."""
+        y = np.zeros(self.m)
+        rc = np.zeros(self.n + self.m)
+        u = np.zeros(self.m)
+        ratios = np.zeros(self.m)
+        bpre = np.zeros(self.m, dtype=np.int32)
+        xb = np.zeros(self.m)
+        N.check(N.lib.lpr_revised_snapshot_read(self._h, _dptr(y), _dptr(rc), _dptr(u),
+                                                _dptr(ratios), _i32ptr(bpre), _dptr(xb)),
+                "lpr_revised_snapshot_read")
+        return y, rc, u, ratios, bpre, xb
+
+    def binv_a_exact(self) -> np.ndarray:
+        out = np.empty((self.m, self.n), dtype=np.float64)
+        N.check(N.lib.lpr_revised_binv_a_exact(self._h, _dptr(out)), "lpr_revised_binv_a_exact")
+        return out
+
+
 class SensState:
     """Device-resident tableau of a SensitivityAnalyzer (lpr_sens_*).  Edits return the
     lpr_sens_outcome of the re-solve."""

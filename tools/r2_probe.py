@@ -71,24 +71,28 @@ def main():
     quick = "--quick" in sys.argv
     m, n = 4096, 8192
     eng = pkg.Engine(0)
-    rows = []
-    for label, fl in (("confined+L2", 0), ("confined+memside", MEMSIDE), ("spread", SPREAD)):
+    NOAVOID, NOHINT = 0x80000, 0x100000
+    heads = (("confined+L2, sweep leaves the XCD", 0), ("same, live word only", NOHINT),
+             ("confined+L2, sweep everywhere", NOAVOID), ("confined+memside", MEMSIDE),
+             ("spread", SPREAD))
+    for label, fl in heads:
         for tile in ((0x08,) if quick else (0x08, 0x24, 0x28, 0x04, 0x10)):
             r = run(eng, m, n, 0x3000 | tile | fl, label=f"ov2 {label} tile {tile:#x}")
             print(json.dumps(r), flush=True)
-            rows.append(r)
     for label, fl in (("confined+L2", 0), ("spread", SPREAD)):
         for tile in ((0x08,) if quick else (0x08, 0x28)):
             r = run(eng, m, n, 0x4000 | tile | fl, label=f"seq {label} tile {tile:#x}")
             print(json.dumps(r), flush=True)
-    r = run(eng, m, n, 0x5008, label="ov (one launch)")
-    print(json.dumps(r), flush=True)
-    r = run(eng, m, n, 0, block=1, warm=32, steps=128, label="one pivot per sweep")
-    print(json.dumps(r), flush=True)
-    for label, v in (("ov2 confined+L2", 0x3008), ("ov2 confined+memside", 0x3008 | MEMSIDE),
-                     ("ov2 spread", 0x3008 | SPREAD), ("seq confined+L2", 0x4008),
-                     ("seq confined+memside", 0x4008 | MEMSIDE), ("seq spread", 0x4008 | SPREAD)):
-        print(json.dumps(stamps(eng, m, n, v, label)), flush=True)
+    if not quick:
+        r = run(eng, m, n, 0x5008, label="ov (one launch)")
+        print(json.dumps(r), flush=True)
+        r = run(eng, m, n, 0, block=1, warm=32, steps=128, label="one pivot per sweep")
+        print(json.dumps(r), flush=True)
+    for label, v in (("ov2 default", 0x3008), ("ov2 live word only", 0x3008 | NOHINT),
+                     ("ov2 sweep everywhere", 0x3008 | NOAVOID),
+                     ("ov2 spread", 0x3008 | SPREAD), ("seq confined+L2", 0x4008)):
+        for rep in range(2):
+            print(json.dumps(stamps(eng, m, n, v, label)), flush=True)
     eng.close()
 
 
