@@ -165,6 +165,13 @@ __device__ __forceinline__ unsigned ov_xcc_id() {
 }
 __device__ __forceinline__ unsigned long long ov_now() { return __builtin_amdgcn_s_memrealtime(); }
 
+// value of `v` in lane `k` (k a compile-time constant) as a wave-uniform scalar
+__device__ __forceinline__ double ov_rl(double v, int k) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), k);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
+    return __hiloint2double(hi, lo);
+}
+
 // arg-min over the G partials, one per lane (G <= 64), every wave on its own
 __device__ __forceinline__ Cand ov_reduce_zparts(const ZPart* bank, int G) {
     const int lane = threadIdx.x & (kWave - 1);
@@ -598,12 +605,6 @@ __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, i
     if ((int)blockIdx.x % spread != 0) return;
     __shared__ double lds_v[16];
     __shared__ int lds_i[16];
-    __shared__ double lds_p[2];
-    __shared__ int s_r[kOvMax];   // rows of the pivots staged by this launch
-    __shared__ int rA[kOvMax];    // rows of the pivots of the block being swept
-    __shared__ double s_fa[kOvMax], s_fn[kOvMax];       // f_t[r] of the earlier pivots
-    __shared__ double s_pa[kOvMax], s_pn[kOvMax];       // p_t[e] of the earlier pivots
-    __shared__ double s_parhs[kOvMax], s_prhs[kOvMax];  // p_t[rhs]: block being swept / this block
     __shared__ int s_pick[2];  // [0] the index a collect returned, [1] it timed out
     const int tid = threadIdx.x, nt = blockDim.x;
     const int g = (int)blockIdx.x / spread;
@@ -656,11 +657,21 @@ __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, i
     }
     double2 myz = have_c ? zrow2[c2_first] : make_double2(0.0, 0.0);
     double myb = have_i ? B.bvec[(size_t)(staged0 & 1) * Rp + i_first] : 0.0;
-    if (tid < kOvMax) {
-        rA[tid] = (tid < kb) ? ci->r[tid] : -1;
-        s_parhs[tid] = (tid < kb) ? prowA[(size_t)tid * ld + rhs] : 0.0;
+    // Workgroup-uniform operands are kept ONE PER LANE (the same in every wave) and read with
+    // v_readlane where a chain needs them: lane t < 16 holds what belongs to pivot t of the block
+    // being swept, lane 16 + t what belongs to pivot t of this block.  One load per wave fetches a
+    // whole operand vector; the chains run on registers and scalars only (no LDS, no barrier).
+    const int lane = tid & (kWave - 1);
+    const int rAv = (lane < kb) ? ci->r[lane] : -1;                          // pivot rows, block A
+    const double parhsAv = (lane < kb) ? prowA[(size_t)lane * ld + rhs] : 0.0;  // p_t[rhs], block A
+    int rNv = -1;            // lane t: pivot row of this block's pivot t
+    double prhsNv = 0.0;     // lane t: p_t[rhs] of this block's pivot t
+    unsigned maskA = 0u, maskN = 0u;  // bit t: this lane's row is the pivot row of pivot t
+#pragma unroll
+    for (int t = 0; t < kOvMax; ++t) {
+        const int rt = __builtin_amdgcn_readlane(rAv, t);
+        maskA |= (have_i && rt == i_first) ? (1u << t) : 0u;
     }
-    __syncthreads();
 
     int32_t pend_out = pend_in;
     int32_t status_out = status;
@@ -739,36 +750,32 @@ __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, i
                 break;
             }
             // ---- column e after all earlier pivots, this lane's row(s); one trip ----
+            // pv: lane t < kb: p_t[e] of the block being swept; lane 16 + t, t < q - 1: p_t[e] of
+            // this block's earlier pivots; every other lane +0.0.  Steps of unused pivots are exact
+            // no-ops (x - (+0 * +0) = x), so both chains are straight-line code of kOvMax steps.
             double cq = have_i ? Tin[(size_t)i_first * ld + e] : 0.0;
-            if (tid < kb) s_pa[tid] = prowA[(size_t)tid * ld + e];
-            if (tid >= 32 && tid - 32 < q - 1) s_pn[tid - 32] = xld(&prowN[(size_t)(tid - 32) * ld + e]);
+            double pv = 0.0;
+            if (lane < kb) pv = prowA[(size_t)lane * ld + e];
+            else if (lane >= kOvMax && lane - kOvMax < q - 1)
+                pv = xld(&prowN[(size_t)(lane - kOvMax) * ld + e]);
             if (STAMP) {
                 __builtin_amdgcn_s_waitcnt(0);
                 OV_STAMP(q, 2);  // this wave's column gather has arrived
+                OV_STAMP(q, 3);
             }
-            __syncthreads();
-            OV_STAMP(q, 3);
 #pragma unroll
             for (int t = 0; t < kOvMax; ++t) {  // through the block being swept
-                if (t < kb) {
-                    if (i_first == rA[t]) {
-                        cq = s_pa[t];
-                    } else {
-                        const double prod = fA[t] * s_pa[t];
-                        cq = cq - prod;
-                    }
-                }
+                const double pt = ov_rl(pv, t);
+                const double prod = fA[t] * pt;
+                const double d = cq - prod;
+                cq = ((maskA >> t) & 1u) ? pt : d;  // i_first == rA[t]: the pivot row
             }
 #pragma unroll
             for (int t = 0; t < kOvMax; ++t) {  // through this block's earlier pivots
-                if (t < q - 1) {
-                    if (i_first == s_r[t]) {
-                        cq = s_pn[t];
-                    } else {
-                        const double prod = myf[t] * s_pn[t];
-                        cq = cq - prod;
-                    }
-                }
+                const double pt = ov_rl(pv, kOvMax + t);
+                const double prod = myf[t] * pt;
+                const double d = cq - prod;
+                cq = ((maskN >> t) & 1u) ? pt : d;
             }
 #pragma unroll
             for (int t = 0; t < kOvMax; ++t)
@@ -789,20 +796,28 @@ __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, i
             }
             for (int i = i_first + G * nt; i < R; i += G * nt) {  // further rows of this lane
                 double c = Tin[(size_t)i * ld + e];
-                for (int t = 0; t < kb; ++t) {
-                    if (i == rA[t]) {
-                        c = s_pa[t];
-                    } else {
-                        const double prod = fcolA[(size_t)t * Rp + i] * s_pa[t];
-                        c = c - prod;
+#pragma unroll
+                for (int t = 0; t < kOvMax; ++t) {
+                    if (t < kb) {
+                        const double pt = ov_rl(pv, t);
+                        if (i == __builtin_amdgcn_readlane(rAv, t)) {
+                            c = pt;
+                        } else {
+                            const double prod = fcolA[(size_t)t * Rp + i] * pt;
+                            c = c - prod;
+                        }
                     }
                 }
-                for (int t = 0; t < q - 1; ++t) {
-                    if (i == s_r[t]) {
-                        c = s_pn[t];
-                    } else {
-                        const double prod = fcolN[(size_t)t * Rp + i] * s_pn[t];
-                        c = c - prod;
+#pragma unroll
+                for (int t = 0; t < kOvMax; ++t) {
+                    if (t < q - 1) {
+                        const double pt = ov_rl(pv, kOvMax + t);
+                        if (i == __builtin_amdgcn_readlane(rNv, t)) {
+                            c = pt;
+                        } else {
+                            const double prod = fcolN[(size_t)t * Rp + i] * pt;
+                            c = c - prod;
+                        }
                     }
                 }
                 hst(&colq[i], c, l2);
@@ -849,52 +864,98 @@ __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, i
                 pend_out = LPR_PIVOT_LIMIT;
                 break;
             }
-            if (tid == 0) s_r[q - 1] = r;
 
             // ---- row r after all earlier pivots, normalised (:199); next Z row; one trip ----
+            // fv: lane t < kb: f_t[r] of the block being swept; lane 16 + t, t < q - 1: f_t[r] of
+            // this block; lane 32: T[r, rhs]; lane 33: the pivot element T[r, e]; lane 34: the Z
+            // row's factor T[0, e]; others +0.0.  The row's RHS entry goes through the same chain
+            // as the lane's own column pair (independent chains, interleaved by the scheduler), so
+            // p_q[rhs] needs neither a lane of its own nor a barrier.
             double2 w = have_c ? Tin2[(size_t)r * ld2 + c2_first] : make_double2(0.0, 0.0);
-            if (tid < kb) s_fa[tid] = fcolA[(size_t)tid * Rp + r];
-            if (tid >= 32 && tid - 32 < q - 1) s_fn[tid - 32] = xld(&fcolN[(size_t)(tid - 32) * Rp + r]);
-            double wr = (tid == 128) ? Tin[(size_t)r * ld + rhs] : 0.0;
-            const double p = xld(&colq[r]);   // the pivot element T[r, e] ...
-            const double f0 = xld(&colq[0]);  // ... and the Z row's factor T[0, e]
+            double fv = 0.0;
+            {
+                const double* src = nullptr;
+                if (lane < kb) src = fcolA + (size_t)lane * Rp + r;
+                else if (lane >= kOvMax && lane - kOvMax < q - 1)
+                    src = fcolN + (size_t)(lane - kOvMax) * Rp + r;
+                else if (lane == 32) src = Tin + (size_t)r * ld + rhs;
+                else if (lane == 33) src = colq + r;
+                else if (lane == 34) src = colq;
+                if (src) fv = xld(src);
+            }
             if (STAMP) {
                 __builtin_amdgcn_s_waitcnt(0);
                 OV_STAMP(q, 8);  // this wave's row gather has arrived
             }
-            __syncthreads();
+            double wr = ov_rl(fv, 32);
+            const double p = ov_rl(fv, 33);   // the pivot element T[r, e] ...
+            const double f0 = ov_rl(fv, 34);  // ... and the Z row's factor T[0, e]
+            // r was the pivot row of earlier pivot t: bit t (wave-uniform)
+            const unsigned ra = (unsigned)__ballot(lane < kb && rAv == r);
+            const unsigned rn = (unsigned)__ballot(lane < q - 1 && rNv == r);
+            if ((ra | rn) == 0u) {  // the common case: r has not been a pivot row in these blocks
+#pragma unroll
+                for (int t = 0; t < kOvMax; ++t) {  // through the block being swept
+                    const double f = ov_rl(fv, t);
+                    const double px = f * pA[t].x;
+                    const double py = f * pA[t].y;
+                    const double pr = f * ov_rl(parhsAv, t);
+                    w.x = w.x - px;
+                    w.y = w.y - py;
+                    wr = wr - pr;
+                }
+#pragma unroll
+                for (int t = 0; t < kOvMax; ++t) {  // through this block's earlier pivots
+                    const double f = ov_rl(fv, kOvMax + t);
+                    const double px = f * myp[t].x;
+                    const double py = f * myp[t].y;
+                    const double pr = f * ov_rl(prhsNv, t);
+                    w.x = w.x - px;
+                    w.y = w.y - py;
+                    wr = wr - pr;
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < kOvMax; ++t) {
+                    if ((ra >> t) & 1u) {
+                        w = pA[t];
+                        wr = ov_rl(parhsAv, t);
+                    } else {
+                        const double f = ov_rl(fv, t);
+                        const double px = f * pA[t].x;
+                        const double py = f * pA[t].y;
+                        const double pr = f * ov_rl(parhsAv, t);
+                        w.x = w.x - px;
+                        w.y = w.y - py;
+                        wr = wr - pr;
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < kOvMax; ++t) {
+                    if ((rn >> t) & 1u) {
+                        w = myp[t];
+                        wr = ov_rl(prhsNv, t);
+                    } else {
+                        const double f = ov_rl(fv, kOvMax + t);
+                        const double px = f * myp[t].x;
+                        const double py = f * myp[t].y;
+                        const double pr = f * ov_rl(prhsNv, t);
+                        w.x = w.x - px;
+                        w.y = w.y - py;
+                        wr = wr - pr;
+                    }
+                }
+            }
+            const double prhs = wr / p;  // p_q[rhs]: every lane works it out for itself
+            if (lane == q - 1) {
+                prhsNv = prhs;
+                rNv = r;
+            }
+            if (have_i && i_first == r) maskN |= 1u << (q - 1);
             Cand n;
             n.v = 0.0;
             n.i = -1;
             if (have_c) {
-#pragma unroll
-                for (int t = 0; t < kOvMax; ++t) {
-                    if (t < kb) {
-                        if (r == rA[t]) {
-                            w = pA[t];
-                        } else {
-                            const double f = s_fa[t];
-                            const double px = f * pA[t].x;
-                            const double py = f * pA[t].y;
-                            w.x = w.x - px;
-                            w.y = w.y - py;
-                        }
-                    }
-                }
-#pragma unroll
-                for (int t = 0; t < kOvMax; ++t) {
-                    if (t < q - 1) {
-                        if (r == s_r[t]) {
-                            w = myp[t];
-                        } else {
-                            const double f = s_fn[t];
-                            const double px = f * myp[t].x;
-                            const double py = f * myp[t].y;
-                            w.x = w.x - px;
-                            w.y = w.y - py;
-                        }
-                    }
-                }
                 const int j = 2 * c2_first;
                 double2 pq;
                 pq.x = (j < C) ? w.x / p : 0.0;  // :199 true division
@@ -921,30 +982,36 @@ __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, i
             for (int c2 = c2_first + G * nt; c2 < ld2; c2 += G * nt) {  // further column pairs
                 double2 ww = Tin2[(size_t)r * ld2 + c2];
                 double2 z = zrow2[c2];
-                for (int t = 0; t < kb; ++t) {
-                    const double2 ps = prowA2[(size_t)t * ld2 + c2];
-                    if (r == rA[t]) {
-                        ww = ps;
-                    } else {
-                        const double f = s_fa[t];
-                        const double px = f * ps.x;
-                        const double py = f * ps.y;
-                        ww.x = ww.x - px;
-                        ww.y = ww.y - py;
+#pragma unroll
+                for (int t = 0; t < kOvMax; ++t) {
+                    if (t < kb) {
+                        const double2 ps = prowA2[(size_t)t * ld2 + c2];
+                        if ((ra >> t) & 1u) {
+                            ww = ps;
+                        } else {
+                            const double f = ov_rl(fv, t);
+                            const double px = f * ps.x;
+                            const double py = f * ps.y;
+                            ww.x = ww.x - px;
+                            ww.y = ww.y - py;
+                        }
                     }
                 }
-                for (int t = 0; t < q - 1; ++t) {
-                    double2 ps;
-                    ps.x = prowN[(size_t)t * ld + 2 * c2];
-                    ps.y = prowN[(size_t)t * ld + 2 * c2 + 1];
-                    if (r == s_r[t]) {
-                        ww = ps;
-                    } else {
-                        const double f = s_fn[t];
-                        const double px = f * ps.x;
-                        const double py = f * ps.y;
-                        ww.x = ww.x - px;
-                        ww.y = ww.y - py;
+#pragma unroll
+                for (int t = 0; t < kOvMax; ++t) {
+                    if (t < q - 1) {
+                        double2 ps;
+                        ps.x = prowN[(size_t)t * ld + 2 * c2];
+                        ps.y = prowN[(size_t)t * ld + 2 * c2 + 1];
+                        if ((rn >> t) & 1u) {
+                            ww = ps;
+                        } else {
+                            const double f = ov_rl(fv, kOvMax + t);
+                            const double px = f * ps.x;
+                            const double py = f * ps.y;
+                            ww.x = ww.x - px;
+                            ww.y = ww.y - py;
+                        }
                     }
                 }
                 const int j = 2 * c2;
@@ -967,33 +1034,7 @@ __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, i
                     n.i = j + 1;
                 }
             }
-            OV_STAMP(q, 9);
-            n = block_cand_min(n, lds_v, lds_i);
-
             // ---- RHS column after this pivot ----
-            if (tid == 128) {
-                for (int t = 0; t < kb; ++t) {
-                    if (r == rA[t]) {
-                        wr = s_parhs[t];
-                    } else {
-                        const double prod = s_fa[t] * s_parhs[t];
-                        wr = wr - prod;
-                    }
-                }
-                for (int t = 0; t < q - 1; ++t) {
-                    if (r == s_r[t]) {
-                        wr = s_prhs[t];
-                    } else {
-                        const double prod = s_fn[t] * s_prhs[t];
-                        wr = wr - prod;
-                    }
-                }
-                const double v = wr / p;
-                s_prhs[q - 1] = v;  // p_q[rhs]: every workgroup works it out for itself
-                lds_p[1] = v;
-            }
-            __syncthreads();
-            const double prhs = lds_p[1];
             if (have_i) {
                 const double prod = cq * prhs;
                 myb = (i_first == r) ? prhs : myb - prod;
@@ -1003,6 +1044,8 @@ __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, i
                 const double prod = colq[i] * prhs;
                 hst(&bnew[i], (i == r) ? prhs : bprev[i] - prod, l2);
             }
+            OV_STAMP(q, 9);
+            n = block_cand_min(n, lds_v, lds_i);
             if (lead && tid == 0) {
                 co->r[q - 1] = r;
                 B.basis[r - 1] = e;  // :142
