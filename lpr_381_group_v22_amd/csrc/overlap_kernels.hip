@@ -172,6 +172,32 @@ __device__ __forceinline__ double ov_rl(double v, int k) {
     return __hiloint2double(hi, lo);
 }
 
+// (value, index) lexicographic minimum over the 64 lanes of a wave, in every lane, with DPP moves
+// (row-local permutes, then the two row broadcasts of gfx9) instead of six rounds of ds_bpermute:
+// the operation is associative and commutative, so the order of combination does not matter.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ Cand ov_dpp_min(Cand c) {
+    Cand o;
+    const int lo = __double2loint(c.v), hi = __double2hiint(c.v);
+    const int olo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+    const int ohi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+    o.i = __builtin_amdgcn_update_dpp(c.i, c.i, CTRL, ROW_MASK, 0xf, false);
+    o.v = __hiloint2double(ohi, olo);
+    return cand_min(c, o);
+}
+__device__ __forceinline__ Cand ov_wave_min(Cand c) {
+    c = ov_dpp_min<0xB1, 0xf>(c);   // quad_perm [1,0,3,2]
+    c = ov_dpp_min<0x4E, 0xf>(c);   // quad_perm [2,3,0,1]
+    c = ov_dpp_min<0x141, 0xf>(c);  // row_half_mirror
+    c = ov_dpp_min<0x140, 0xf>(c);  // row_mirror: every row of 16 holds its minimum
+    c = ov_dpp_min<0x142, 0xa>(c);  // row_bcast15 into rows 1 and 3
+    c = ov_dpp_min<0x143, 0xc>(c);  // row_bcast31 into rows 2 and 3: lane 63 holds the minimum
+    Cand r;
+    r.v = ov_rl(c.v, 63);
+    r.i = __builtin_amdgcn_readlane(c.i, 63);
+    return r;
+}
+
 // arg-min over the G partials, one per lane (G <= 64), every wave on its own
 __device__ __forceinline__ Cand ov_reduce_zparts(const ZPart* bank, int G) {
     const int lane = threadIdx.x & (kWave - 1);
@@ -576,7 +602,34 @@ __device__ __forceinline__ Cand gr_collect(const unsigned long long* base, int G
         c.v = none;
         c.i = -1;
     }
-    return wave_cand_min(c);
+    return ov_wave_min(c);
+}
+
+// One phase of a head ends: every wave reduces its lanes' candidates and leaves the result in its
+// LDS slot, waits until its own stores of the phase have been acknowledged, and meets the others at
+// ONE workgroup barrier; then lane 0 combines the slots and publishes the workgroup's partial.
+__device__ __forceinline__ void ov_publish_min(Cand c, double* lds_v, int* lds_i,
+                                               unsigned long long* g3, unsigned epoch, bool l2) {
+    c = ov_wave_min(c);
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    if (lane == 0) {
+        lds_v[wave] = c.v;
+        lds_i[wave] = c.i;
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        Cand r;
+        r.v = lds_v[0];
+        r.i = lds_i[0];
+        for (int w = 1; w < (int)blockDim.x / kWave; ++w) {
+            Cand o;
+            o.v = lds_v[w];
+            o.i = lds_i[w];
+            r = cand_min(r, o);
+        }
+        gr_publish(g3, epoch, r.v, r.i, l2);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -832,14 +885,10 @@ __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, i
             // this workgroup's (ratio, row) minimum -> its partial, published once its column slice
             // has drained; then wave 0 collects the G partials: the leaving row (:169-191)
             OV_STAMP(q, 4);
-            rc = block_cand_min(rc, lds_v, lds_i);
             OV_STAMP(q, 5);
-            __builtin_amdgcn_s_waitcnt(0);
-            __syncthreads();
-            OV_STAMP(q, 6);  // column slice drained
-            if (tid == 0)
-                gr_publish(B.gran + (size_t)(2 * kOvGroups + g) * 3, (unsigned)(2 * pidx + 2), rc.v,
-                           rc.i, l2);
+            ov_publish_min(rc, lds_v, lds_i, B.gran + (size_t)(2 * kOvGroups + g) * 3,
+                           (unsigned)(2 * pidx + 2), l2);
+            OV_STAMP(q, 6);  // column slice drained, partial published
             if (tid < kWave) {
                 int fail = 0;
                 const Cand rr = gr_collect(B.gran + (size_t)2 * 3 * kOvGroups, G,
@@ -1045,7 +1094,6 @@ __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, i
                 hst(&bnew[i], (i == r) ? prhs : bprev[i] - prod, l2);
             }
             OV_STAMP(q, 9);
-            n = block_cand_min(n, lds_v, lds_i);
             if (lead && tid == 0) {
                 co->r[q - 1] = r;
                 B.basis[r - 1] = e;  // :142
@@ -1060,12 +1108,10 @@ __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, i
             // head is collected by the next launch, whose workgroups may sit on another XCD: that
             // one always goes through the memory side.
             OV_STAMP(q, 10);
-            __builtin_amdgcn_s_waitcnt(0);
-            __syncthreads();
-            OV_STAMP(q, 11);  // row slice drained
-            if (tid == 0)
-                gr_publish(B.gran + ((size_t)((pidx + 1) & 1) * kOvGroups + g) * 3,
-                           (unsigned)(2 * (pidx + 1) + 1), n.v, n.i, l2 && q < K);
+            ov_publish_min(n, lds_v, lds_i,
+                           B.gran + ((size_t)((pidx + 1) & 1) * kOvGroups + g) * 3,
+                           (unsigned)(2 * (pidx + 1) + 1), l2 && q < K);
+            OV_STAMP(q, 11);  // row slice drained, partial published
         }
     }
 #undef OV_STAMP
@@ -1421,7 +1467,9 @@ __global__ __launch_bounds__(kOvNT) void k_ov_sweep(const OvBuffers B,
                                                     const double* __restrict__ fcol_ro,
                                                     const double* __restrict__ prow_ro, int ld,
                                                     int R, int Rp) {
-    ov_tiles<TR, DB, true>(B, fcol_ro, prow_ro, ld, R, Rp, 0, 1, -1, 0);
+    // nothing runs beside the in-place sweep: one workgroup per tile, dealt by the hardware (the
+    // queue's counter costs a burst of ~1000 atomics on one word at the start of every sweep)
+    ov_tiles<TR, DB, true>(B, fcol_ro, prow_ro, ld, R, Rp, 0, 1, (int)blockIdx.x, 0);
 }
 
 }  // namespace lpr
@@ -1632,7 +1680,7 @@ void ov_launch_sweep(lpr_tableau* t, int tr) {
     hipStream_t s = t->eng->stream;
     const int nct = (t->ld / 2 + kOvNT - 1) / kOvNT;
     const int nrt = (t->rows + kOvTileRows - 1) / kOvTileRows;
-    const dim3 grid(ov_sweep_grid(t, nct * nrt)), blk(kOvNT);
+    const dim3 grid(nct * nrt), blk(kOvNT);
 #define LPR_OV_SWEEP(TR, DB)                                                                     \
     hipLaunchKernelGGL((k_ov_sweep<TR, DB>), grid, blk, 0, s, c->b, c->b.fcol, c->b.prow, t->ld,  \
                        t->rows, c->Rp)
