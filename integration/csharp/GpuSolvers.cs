@@ -111,11 +111,45 @@ namespace LPR_381_Group_V22.Simplex
                 isMinimization ? 1 : 0, out solver), "lpr_revised_create");
         }
 
+        /// <summary>Above this many table entries per snapshot none are kept (the reference would
+        /// write megabytes of text per pivot); set before Solve() to force either way.</summary>
+        public bool KeepSnapshots { get; set; }
+
         public void Solve()
         {
-            var opts = new LprSolveOpts();
-            NativeMethods.ThrowIfError(NativeMethods.lpr_revised_solve(solver, ref opts, out var res), "lpr_revised_solve");
-            switch ((LprStatus)res.status)
+            int status;
+            if (KeepSnapshots || (long)m * (n + m + 1) <= 4096)
+            {
+                // one pass of the reference's while-loop per call; after every pivot and at the
+                // optimum the numbers of CaptureSnapshot (:294-387) are read back and formatted by
+                // the reference's own StringBuilder code (kept as FormatSnapshot, unchanged)
+                int iteration = 0;
+                while (true)
+                {
+                    NativeMethods.ThrowIfError(NativeMethods.lpr_revised_step(solver, out var info), "lpr_revised_step");
+                    status = info.status;
+                    if (status != (int)LprStatus.PivotLimit && status != (int)LprStatus.Optimal) break;
+                    double[] y = new double[m], rc = new double[n + m], u = new double[m], ratios = new double[m], xB = new double[m];
+                    int[] basisPre = new int[m];
+                    NativeMethods.lpr_revised_snapshot_read(solver, y, rc, u, ratios, basisPre, xB);
+                    var binvA = new double[m, n]; var binv = new double[m, m];
+                    NativeMethods.lpr_revised_binv_a_exact(solver, binvA);
+                    NativeMethods.lpr_revised_binv_read(solver, binv);
+                    bool optimal = status == (int)LprStatus.Optimal;
+                    if (optimal) { u = new double[m]; for (int i = 0; i < m; i++) ratios[i] = double.PositiveInfinity; basisPre = BasicVariables.ToArray(); }
+                    IterationSnapshots.Add(FormatSnapshot(optimal ? "Optimal" : $"Iteration {++iteration}", xB, y,
+                        rc.Take(n).ToArray(), rc.Skip(n).ToArray(), info.entering, info.entering_rc_pre, u, ratios,
+                        basisPre.ToList(), info.leaving_row, info.leaving_var, info.z_working, info.z_original, binvA, binv));
+                    if (optimal) break;
+                }
+            }
+            else
+            {
+                var opts = new LprSolveOpts();
+                NativeMethods.ThrowIfError(NativeMethods.lpr_revised_solve(solver, ref opts, out var res), "lpr_revised_solve");
+                status = res.status;
+            }
+            switch ((LprStatus)status)
             {
                 case LprStatus.Optimal:
                     var x = new double[n];
@@ -130,6 +164,16 @@ namespace LPR_381_Group_V22.Simplex
         }
 
         public List<int> BasicVariables { get { var b = new int[m]; NativeMethods.lpr_revised_basis_read(solver, b); return b.ToList(); } }
+
+        // The body of the reference's CaptureSnapshot (RevisedPrimalSimplexSolver.cs:310-386) with
+        // its two matrix products replaced by the arguments binvA / binv: keep the reference's
+        // StringBuilder statements here verbatim (NumFormat.N3, VarLabel stay in the project).
+        private string FormatSnapshot(string title, double[] xB, double[] y, double[] rcX_post, double[] rcS_post,
+            int enteringIdx, double enteringRC_pre, double[] u_pre, double[] ratios_pre, List<int> basisForRatios_Pre,
+            int leavingRow, int leavingVarIndex_Pre, double zWorking, double zOriginal, double[,] BInvA, double[,] BInv)
+        {
+            throw new NotImplementedException("paste RevisedPrimalSimplexSolver.cs:310-386 here, minus lines 360-361");
+        }
 
         /// <summary>B^-1 * A of CaptureSnapshot (:360) on the fp64 matrix cores.</summary>
         public double[,] BInverseTimesA() { var p = new double[m, n]; NativeMethods.lpr_revised_binv_a(solver, p, out _); return p; }

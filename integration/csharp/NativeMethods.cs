@@ -28,6 +28,13 @@ namespace LPR_381_Group_V22.Native
     }
 
     [StructLayout(LayoutKind.Sequential)]
+    internal struct LprRevisedSnapshotInfo
+    {
+        public int status, entering, leaving_row, leaving_var;
+        public double entering_rc_pre, z_working, z_original;
+    }
+
+    [StructLayout(LayoutKind.Sequential)]
     internal struct LprRevisedResult
     {
         public int status; public int reserved; public long iterations; public long total_iterations; public double z;
@@ -78,6 +85,11 @@ namespace LPR_381_Group_V22.Native
         internal static extern int lpr_revised_create(IntPtr engine, int n, int m, double[] objective, double[,] A, int lda, double[] b, int is_min, out IntPtr solver);
         [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_revised_destroy(IntPtr solver);
         [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_revised_solve(IntPtr solver, ref LprSolveOpts opts, out LprRevisedResult res);
+        // IterationSnapshots (RevisedPrimalSimplexSolver.cs:36, CaptureSnapshot :294-387)
+        [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_revised_step(IntPtr solver, out LprRevisedSnapshotInfo info);
+        [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_revised_snapshot_read(IntPtr solver, double[] y, double[] rc, double[] u, double[] ratios, int[] basisPre, double[] xB);
+        [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_revised_binv_a_exact(IntPtr solver, double[,] product);
+        [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_revised_binv_read(IntPtr solver, double[,] binv);
         [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_revised_solution(IntPtr solver, double[] x, out double z);
         [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_revised_basis_read(IntPtr solver, int[] basis);
         [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_revised_binv_read(IntPtr solver, double[,] binv);

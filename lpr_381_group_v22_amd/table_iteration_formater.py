@@ -106,8 +106,18 @@ def N3(x: float) -> str:
             return "0"
         if abs(rr) < 1e15:
             return str(int(rr))
-        return repr(rr)
+        return _dotnet_g15_scientific(rr)
     return _custom_0_hashes(r)
+
+
+def _dotnet_g15_scientific(v: float) -> str:
+    """double.ToString() on .NET Framework for |v| >= 1e15: "G" with 15 significant digits falls
+    back to scientific notation, mantissa without trailing zeros, exponent sign and at least two
+    digits ("1E+15", "1.23456789012346E+17")."""
+    mant, exp = f"{abs(v):.14e}".split("e")
+    mant = mant.rstrip("0").rstrip(".")
+    e = int(exp)
+    return ("-" if v < 0 else "") + f"{mant}E{'+' if e >= 0 else '-'}{abs(e):02d}"
 
 
 def Format(tab: np.ndarray, numOriginalVars: int, title: str,

@@ -65,6 +65,12 @@ void orc_extract_solution(const double* T, int R, int C, int n, double* x, doubl
 void orc_matmul_skip(const double* A, int rA, int cA, const double* B, int cB, double* R);
 /* UpdateBInverse :264-275 (scratch: m*m doubles).  0 or ORC_PIVOT_TOO_SMALL. */
 int orc_update_binverse(double* Binv, int m, int pivotRow, const double* u, double* scratch);
+/* CaptureSnapshot (:294-387) as numbers, one record per snapshot; layout in oracle_revised.c */
+int64_t orc_revised_trace_stride(int n, int m);
+int orc_revised_solve_trace(int n, int m, const double* objective, const double* A,
+                            const double* b, int is_min, int64_t max_iter, double* x,
+                            double* finalZ, int32_t* basis, double* trace, int64_t cap,
+                            int64_t* snapshots, int64_t* iterations);
 /* ctor :41-80 + Solve :82-251 + ExtractSolution :277-287; see oracle_revised.c */
 int orc_revised_solve(int n, int m, const double* objective, const double* A, const double* b,
                       int is_min, int64_t max_iter, double* x, double* finalZ, int32_t* basis,

@@ -98,10 +98,82 @@ static double dotnet_max0(double v) { return (0.0 > v) ? 0.0 : v; }
  *   log_row/log_enter/log_leave: per iteration (leavingRow 0-based, entering var, leaving var).
  * Returns the status; *iterations = completed pivots.
  */
+/* One CaptureSnapshot call (:294-387) as numbers: what the C# formats into the text block.
+ * Record layout (doubles; indices are exact in a double), S = orc_revised_trace_stride(n, m):
+ *   [0] enteringIdx  [1] leavingRow  [2] leavingVarIndex_Pre  [3] enteringRC_pre  [4] zWorking
+ *   [5] zOriginal    then y[m], rcX[n], rcS[m], u_pre[m], ratios_pre[m], basisForRatios_Pre[m],
+ *   basicVariables (post)[m], xB[m], BInvA[m*n] (MultiplyMatrices(BInverse, A) :360), BInv[m*m]. */
+int64_t orc_revised_trace_stride(int n, int m) {
+    return 6 + (int64_t)m + n + m + m + m + m + m + m + (int64_t)m * n + (int64_t)m * m;
+}
+
+typedef struct {
+    double* buf;     /* cap * stride doubles, or NULL: no trace */
+    int64_t cap;
+    int64_t count;   /* snapshots the C# would have appended (may exceed cap) */
+} rev_trace;
+
+static void trace_snapshot(rev_trace* tr, int n, int m, int entering, int leavingRow,
+                           int leavingVarPre, double rcPre, double zWorking, double zOriginal,
+                           const double* y, const double* rcX, const double* rcS, const double* u,
+                           const double* ratios, const int* basisPre, const int* basic,
+                           const double* xB, const double* Binv, const double* A) {
+    if (!tr || !tr->buf) return;
+    if (tr->count < tr->cap) {
+        double* r = tr->buf + tr->count * orc_revised_trace_stride(n, m);
+        r[0] = entering; r[1] = leavingRow; r[2] = leavingVarPre;
+        r[3] = rcPre; r[4] = zWorking; r[5] = zOriginal;
+        r += 6;
+        memcpy(r, y, sizeof(double) * m); r += m;
+        memcpy(r, rcX, sizeof(double) * n); r += n;
+        memcpy(r, rcS, sizeof(double) * m); r += m;
+        memcpy(r, u, sizeof(double) * m); r += m;
+        memcpy(r, ratios, sizeof(double) * m); r += m;
+        for (int i = 0; i < m; i++) r[i] = basisPre[i];
+        r += m;
+        for (int i = 0; i < m; i++) r[i] = basic[i];
+        r += m;
+        memcpy(r, xB, sizeof(double) * m); r += m;
+        orc_matmul_skip(Binv, m, m, A, n, r); /* :360 */
+        r += (size_t)m * n;
+        memcpy(r, Binv, sizeof(double) * (size_t)m * m);
+    }
+    tr->count++;
+}
+
+static int revised_core(int n, int m, const double* objective, const double* A, const double* b,
+                        int is_min, int64_t max_iter, double* x, double* finalZ, int32_t* basis,
+                        double* Binv_out, double* xB_out, int32_t* log_row, int32_t* log_enter,
+                        int32_t* log_leave, int64_t log_cap, int64_t* iterations, rev_trace* tr);
+
 int orc_revised_solve(int n, int m, const double* objective, const double* A, const double* b,
                       int is_min, int64_t max_iter, double* x, double* finalZ, int32_t* basis,
                       double* Binv_out, double* xB_out, int32_t* log_row, int32_t* log_enter,
                       int32_t* log_leave, int64_t log_cap, int64_t* iterations) {
+    return revised_core(n, m, objective, A, b, is_min, max_iter, x, finalZ, basis, Binv_out, xB_out,
+                        log_row, log_enter, log_leave, log_cap, iterations, NULL);
+}
+
+/* The same solve, also recording every CaptureSnapshot (:232-247 after each pivot, :127-143 at the
+ * optimum) into trace[cap * stride]; *snapshots = how many the C# list would hold. */
+int orc_revised_solve_trace(int n, int m, const double* objective, const double* A,
+                            const double* b, int is_min, int64_t max_iter, double* x,
+                            double* finalZ, int32_t* basis, double* trace, int64_t cap,
+                            int64_t* snapshots, int64_t* iterations) {
+    rev_trace tr;
+    tr.buf = trace;
+    tr.cap = cap;
+    tr.count = 0;
+    int st = revised_core(n, m, objective, A, b, is_min, max_iter, x, finalZ, basis, NULL, NULL,
+                          NULL, NULL, NULL, 0, iterations, &tr);
+    if (snapshots) *snapshots = tr.count;
+    return st;
+}
+
+static int revised_core(int n, int m, const double* objective, const double* A, const double* b,
+                        int is_min, int64_t max_iter, double* x, double* finalZ, int32_t* basis,
+                        double* Binv_out, double* xB_out, int32_t* log_row, int32_t* log_enter,
+                        int32_t* log_leave, int64_t log_cap, int64_t* iterations, rev_trace* tr) {
     if (n <= 0 || m <= 0) return ORC_BAD_ARGUMENT; /* :43-44 */
     int status = ORC_OK_OPTIMAL;
     double* c = (double*)malloc(sizeof(double) * n);
@@ -117,6 +189,9 @@ int orc_revised_solve(int n, int m, const double* objective, const double* A, co
     int* basic = (int*)malloc(sizeof(int) * m);
     int* nonbasic = (int*)malloc(sizeof(int) * (n + m)); /* the C# List<int>, in its own order */
     int* sorted = (int*)malloc(sizeof(int) * (n + m));
+    double* ratios = (double*)malloc(sizeof(double) * m);
+    int* basisPre = (int*)malloc(sizeof(int) * m);
+    double* xtmp = (double*)calloc(n, sizeof(double));
     int nnb = 0;
     int64_t iteration = 0;
 
@@ -163,7 +238,18 @@ int orc_revised_solve(int n, int m, const double* objective, const double* A, co
             }
         }
 
-        if (enteringIdx == -1) { status = ORC_OK_OPTIMAL; break; } /* :124-146 */
+        if (enteringIdx == -1) { /* :124-146: ExtractSolution, then the "Optimal" snapshot */
+            status = ORC_OK_OPTIMAL;
+            if (tr && tr->buf) {
+                memset(xtmp, 0, sizeof(double) * n);
+                for (int i = 0; i < m; i++)
+                    if (basic[i] < n) xtmp[basic[i]] = dotnet_max0(xB[i]);
+                for (int i = 0; i < m; i++) { u[i] = 0.0; ratios[i] = INFINITY; } /* :133-134 */
+                trace_snapshot(tr, n, m, -1, -1, -1, 0.0, dot(cB, xB, m), dot(objective, xtmp, n),
+                               y, rcX, rcS, u, ratios, basic, basic, xB, Binv, A);
+            }
+            break;
+        }
         if (max_iter > 0 && iteration >= max_iter) { status = ORC_PIVOT_LIMIT; break; }
 
         /* :149-151 direction */
@@ -181,12 +267,15 @@ int orc_revised_solve(int n, int m, const double* objective, const double* A, co
         for (int i = 0; i < m; i++) {
             if (u[i] > EPS) {
                 double ratio = xB[i] / u[i];
+                ratios[i] = ratio; /* :161 */
                 if (ratio < bestRatio - EPS ||
                     (fabs(ratio - bestRatio) <= EPS &&
                      (leavingRow == -1 || basic[i] < basic[leavingRow]))) {
                     bestRatio = ratio;
                     leavingRow = i;
                 }
+            } else {
+                ratios[i] = INFINITY; /* :174 */
             }
         }
         if (leavingRow == -1) { status = ORC_UNBOUNDED; break; } /* :178-179 */
@@ -198,6 +287,9 @@ int orc_revised_solve(int n, int m, const double* objective, const double* A, co
             if (log_enter) log_enter[iteration] = enteringIdx;
             if (log_leave) log_leave[iteration] = leavingVar;
         }
+
+        for (int i = 0; i < m; i++) basisPre[i] = basic[i]; /* :186 */
+        double enteringRC_pre = (enteringIdx < n) ? rcX[enteringIdx] : rcS[enteringIdx - n];
 
         /* :194-198 bookkeeping */
         basic[leavingRow] = enteringIdx;
@@ -215,6 +307,21 @@ int orc_revised_solve(int n, int m, const double* objective, const double* A, co
 
         int rc2 = orc_update_binverse(Binv, m, leavingRow, u, scratch); /* :215 */
         if (rc2 != 0) { status = rc2; break; }
+        if (tr && tr->buf) { /* :217-247: post-pivot quantities, then the snapshot */
+            mat_vec(Binv, m, m, b, xB);
+            vec_mat(cB, Binv, m, m, y);
+            for (int j = 0; j < n; j++) {
+                for (int i = 0; i < m; i++) col[i] = A[(size_t)i * n + j];
+                rcX[j] = c[j] - dot(y, col, m);
+            }
+            for (int k = 0; k < m; k++) rcS[k] = -y[k];
+            memset(xtmp, 0, sizeof(double) * n); /* ComputeOriginalZFromCurrentBasis :253-262 */
+            for (int i = 0; i < m; i++)
+                if (basic[i] < n) xtmp[basic[i]] = dotnet_max0(xB[i]);
+            trace_snapshot(tr, n, m, enteringIdx, leavingRow, leavingVar, enteringRC_pre,
+                           dot(cB, xB, m), dot(objective, xtmp, n), y, rcX, rcS, u, ratios,
+                           basisPre, basic, xB, Binv, A);
+        }
         iteration++; /* :249 */
     }
 
@@ -235,5 +342,6 @@ int orc_revised_solve(int n, int m, const double* objective, const double* A, co
 
     free(c); free(Binv); free(scratch); free(cB); free(xB); free(y); free(rcX); free(rcS);
     free(col); free(u); free(basic); free(nonbasic); free(sorted);
+    free(ratios); free(basisPre); free(xtmp);
     return status;
 }

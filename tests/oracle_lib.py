@@ -248,6 +248,41 @@ class Oracle:
         return dict(status=st, iterations=it.value, x=x, z=z.value, basis=basis, Binv=Binv,
                     xB=xB, log=np.stack([lr[:k], le[:k], ll[:k]], axis=1))
 
+    def revised_trace(self, objective, A, b, is_min=False, max_iter=0, cap=64):
+        """Every CaptureSnapshot (:294-387) as a dict of numbers (layout: oracle_revised.c)."""
+        obj = np.ascontiguousarray(objective, dtype=np.float64)
+        A = np.ascontiguousarray(A, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        m, n = A.shape
+        self.lib.orc_revised_trace_stride.restype = C.c_int64
+        S = self.lib.orc_revised_trace_stride(n, m)
+        buf = np.zeros(cap * S)
+        x = np.zeros(n)
+        z = C.c_double()
+        basis = np.zeros(m, dtype=np.int32)
+        ns, it = C.c_int64(), C.c_int64()
+        st = self.lib.orc_revised_solve_trace(n, m, _dp(obj), _dp(A), _dp(b), 1 if is_min else 0,
+                                              C.c_int64(max_iter), _dp(x), C.byref(z), _ip(basis),
+                                              _dp(buf), C.c_int64(cap), C.byref(ns), C.byref(it))
+        snaps = []
+        for k in range(min(ns.value, cap)):
+            r = buf[k * S:(k + 1) * S]
+            o = 6
+            d = dict(entering=int(r[0]), leaving_row=int(r[1]), leaving_var=int(r[2]),
+                     rc_pre=r[3], z_working=r[4], z_original=r[5])
+            for name, ln in (("y", m), ("rcX", n), ("rcS", m), ("u_pre", m), ("ratios_pre", m),
+                             ("basis_pre", m), ("basis_post", m), ("xB", m)):
+                d[name] = r[o:o + ln].copy()
+                o += ln
+            d["BInvA"] = r[o:o + m * n].reshape(m, n).copy()
+            o += m * n
+            d["BInv"] = r[o:o + m * m].reshape(m, m).copy()
+            d["basis_pre"] = d["basis_pre"].astype(np.int32)
+            d["basis_post"] = d["basis_post"].astype(np.int32)
+            snaps.append(d)
+        return dict(status=st, iterations=it.value, snapshots=snaps, count=ns.value, x=x,
+                    z=z.value, basis=basis)
+
     # ---- generator ----
     def u01(self, seed, stream, i, j) -> float:
         return self.lib.orc_u01(seed, stream, i, j)

@@ -228,8 +228,27 @@ class PyRevised:
         self.status = None
         self.FinalZ = 0.0
         self.SolutionVector = []
+        self.snapshots = []  # CaptureSnapshot (:294-387) as dicts of numbers, when capture=True
 
-    def solve(self, max_iter=0):
+    def _z_original(self):  # ComputeOriginalZFromCurrentBasis :253-262
+        x = [0.0] * self.n
+        for i in range(self.m):
+            v = self.basic[i]
+            if v < self.n:
+                x[v] = 0.0 if 0.0 > self.xB[i] else self.xB[i]
+        return _dot(self.cOrig, x)
+
+    def _capture(self, title, y, rcX, rcS, entering, rc_pre, u_pre, ratios_pre, basis_pre,
+                 leaving_row, leaving_var, z_original):
+        self.snapshots.append(dict(
+            title=title, y=list(y), rcX=list(rcX), rcS=list(rcS), entering=entering,
+            rc_pre=rc_pre, u_pre=list(u_pre), ratios_pre=list(ratios_pre),
+            basis_pre=list(basis_pre), leaving_row=leaving_row, leaving_var=leaving_var,
+            z_working=_dot(self.cB, self.xB), z_original=z_original, xB=list(self.xB),
+            basis_post=list(self.basic), BInvA=_mat_mul_skip(self.Binv, self.A),
+            BInv=[list(r) for r in self.Binv]))
+
+    def solve(self, max_iter=0, capture=False):
         n, m = self.n, self.m
         it = 0
         while True:
@@ -258,6 +277,9 @@ class PyRevised:
                 self.SolutionVector = x
                 self.FinalZ = _dot(self.cOrig, x)
                 self.status = "optimal"
+                if capture:  # :127-143
+                    self._capture("Optimal", y, rcX, rcS, -1, 0.0, [0.0] * m, [math.inf] * m,
+                                  self.basic, -1, -1, self.FinalZ)
                 return self.status
             if max_iter > 0 and it >= max_iter:
                 self.status = "limit"
@@ -268,9 +290,11 @@ class PyRevised:
                 u = [self.Binv[i][entering - n] for i in range(m)]
             leaving = -1
             best_ratio = DBL_MAX
+            ratios = [math.inf] * m
             for i in range(m):
                 if u[i] > REV_EPS:
                     ratio = self.xB[i] / u[i]
+                    ratios[i] = ratio
                     if ratio < best_ratio - REV_EPS or \
                             (abs(ratio - best_ratio) <= REV_EPS and
                              (leaving == -1 or self.basic[i] < self.basic[leaving])):
@@ -284,6 +308,8 @@ class PyRevised:
                 self.status = "entering_already_basic"
                 return self.status
             self.log.append((leaving, entering, leaving_var))
+            basis_pre = list(self.basic)
+            rc_pre = rcX[entering] if entering < n else rcS[entering - n]
             self.basic[leaving] = entering
             self.nonbasic.remove(entering)
             if leaving_var not in self.nonbasic:
@@ -297,7 +323,109 @@ class PyRevised:
             for i in range(m):
                 E[i][leaving] = (1.0 / pivot) if i == leaving else (-u[i] / pivot)
             self.Binv = _mat_mul_skip(E, self.Binv)
+            if capture:  # :217-247
+                self.xB = _mat_vec(self.Binv, self.b)
+                y2 = _vec_mat(self.cB, self.Binv)
+                rcX2 = [self.c[j] - _dot(y2, [self.A[i][j] for i in range(m)]) for j in range(n)]
+                rcS2 = [-y2[k] for k in range(m)]
+                self._capture(f"Iteration {it + 1}", y2, rcX2, rcS2, entering, rc_pre, u, ratios,
+                              basis_pre, leaving, leaving_var, self._z_original())
             it += 1
+
+
+# --------------------------------------------------------------------------------------------
+# CaptureSnapshot's text (:294-387) and NumFormat.N3 (:451-466), restated for the tests
+# --------------------------------------------------------------------------------------------
+def py_round3_away(x: float) -> float:
+    """Math.Round(x, 3, MidpointRounding.AwayFromZero) on .NET Framework (Math.InternalRound):
+    scale by 10^3, split off the fraction, bump when |fraction| >= 0.5, unscale."""
+    if math.isnan(x) or math.isinf(x) or abs(x) >= 1e16:
+        return x
+    v = x * 1000.0
+    frac, whole = math.modf(v)
+    if abs(frac) >= 0.5:
+        whole += math.copysign(1.0, frac)
+    return whole / 1000.0
+
+
+def py_round_even(x: float) -> float:
+    """Math.Round(double): to the nearest integer, ties to even."""
+    if math.isnan(x) or math.isinf(x):
+        return x
+    f = math.floor(x)
+    d = x - f
+    if d > 0.5 or (d == 0.5 and f % 2.0 != 0.0):
+        f += 1.0
+    return math.copysign(f, x) if f == 0.0 else f
+
+
+def py_n3(x: float) -> str:
+    from decimal import ROUND_HALF_UP, Decimal
+    if abs(x) < 1e-12:
+        x = 0.0
+    r = py_round3_away(x)
+    ri = py_round_even(r)
+    if abs(r - ri) < 1e-12:
+        # double.ToString() of an integral value: 15 significant digits, no exponent below 1e15
+        if ri == 0:
+            return "0"
+        if abs(ri) < 1e15:
+            return "%d" % int(ri)
+        # at 1e15 the general format switches to scientific: 15 significant digits, then E+xx
+        from decimal import Context, ROUND_HALF_EVEN
+        tup = Context(prec=15, rounding=ROUND_HALF_EVEN).create_decimal(Decimal(abs(ri))).as_tuple()
+        digits = "".join(str(k) for k in tup.digits)
+        exp10 = len(digits) - 1 + tup.exponent
+        digits = digits.rstrip("0") or "0"
+        mant = digits[0] + ("." + digits[1:] if len(digits) > 1 else "")
+        return ("-" if ri < 0 else "") + mant + ("E+%02d" % exp10)
+    # ToString("0.###"): the 15-significant-digit decimal image, rounded half away at 3 decimals
+    d = Decimal("%.15g" % r).quantize(Decimal("0.001"), rounding=ROUND_HALF_UP)
+    t = format(d, "f").rstrip("0").rstrip(".")
+    return "0" if t in ("-0", "") else t
+
+
+def py_var_label(idx: int, n: int) -> str:  # :289-292
+    return f"x{idx + 1}" if idx < n else f"S{idx - n + 1}"
+
+
+def py_snapshot_text(snap: dict, n: int, m: int, is_min: bool) -> str:
+    nl = "\r\n"
+    t = "\t"
+    out = [snap["title"], nl, "Current Tableau (Revised Simplex)", nl,
+           "Problem type: " + ("MIN (solving by MAX of -c)" if is_min else "MAX"), nl, nl,
+           "Dual prices (y = c_B^T B^{-1}):", nl, t.join(py_n3(v) for v in snap["y"]), nl, nl,
+           "Reduced costs:", nl, "  x: ", t.join(py_n3(v) for v in snap["rcX"]), nl,
+           "  s: ", t.join(py_n3(v) for v in snap["rcS"]), nl, nl]
+    e = snap["entering"]
+    if e >= 0:
+        el = py_var_label(e, n)
+        out += [f"Entering variable (chosen pre-pivot): {el}  (reduced cost pre = "
+                f"{py_n3(snap['rc_pre'])})", nl,
+                "Direction u = B^{-1} a_enter (pre-pivot):", nl,
+                t.join(py_n3(v) for v in snap["u_pre"]), nl, nl,
+                "Ratio test (xB_i / u_i; \u221e if u_i \u2264 0)  [labels = pre-pivot basis]:", nl]
+        for i in range(m):
+            rv = snap["ratios_pre"][i]
+            out += [py_var_label(snap["basis_pre"][i], n), ": ",
+                    "\u221e" if rv == math.inf else py_n3(rv), nl]
+        if snap["leaving_row"] >= 0 and snap["leaving_var"] >= 0:
+            out += [f"Pivot (pre\u2192post): {py_var_label(snap['leaving_var'], n)}  \u2192  {el}"
+                    f"    (pivot = {py_n3(snap['u_pre'][snap['leaving_row']])})", nl, nl]
+    out += [f"Working objective Z_working (maxified): {py_n3(snap['z_working'])}", nl,
+            f"Original objective Z_original ({'MIN' if is_min else 'MAX'}): "
+            f"{py_n3(snap['z_original'])}", nl, nl]
+    out += ["Table", t] + [f"x{j + 1}{t}" for j in range(n)] + [f"S{j + 1}{t}" for j in range(m)] \
+        + ["RHS", nl]
+    out += ["Z~", t] + [py_n3(v) + t for v in snap["rcX"]] + [py_n3(v) + t for v in snap["rcS"]] \
+        + [py_n3(snap["z_working"]), nl]
+    for i in range(m):
+        out += [py_var_label(snap["basis_post"][i], n), t]
+        out += [py_n3(v) + t for v in snap["BInvA"][i]]
+        out += [py_n3(v) + t for v in snap["BInv"][i]]
+        out += [py_n3(snap["xB"][i]), nl]
+    out += ["Basic Variables: ", ", ".join(py_var_label(v, n) for v in snap["basis_post"]), nl]
+    return "".join(out)
 
 
 # --------------------------------------------------------------------------------------------

@@ -6,7 +6,8 @@ import numpy as np
 import pytest
 
 import lp_cases
-from ref_py import PyConstraint, PyRevised, parse_model_text, program_option2_constraints
+from ref_py import (PyConstraint, PyRevised, parse_model_text, program_option2_constraints, py_n3,
+                    py_snapshot_text)
 
 STATUS = {0: "optimal", 1: "unbounded", 2: "infeasible_basis", 3: "pivot_too_small",
           4: "entering_already_basic", 5: "limit"}
@@ -103,3 +104,66 @@ def test_matmul_skip_semantics(oracle):
                 want[i] = want[i] + Az[i, k] * B[k]
     assert R.tobytes() == want.tobytes()
     assert not np.array_equal(R, A @ B)
+
+
+SNAP_KEYS = ("y", "rcX", "rcS", "u_pre", "ratios_pre", "xB")
+
+
+@pytest.mark.parametrize("name,case", revised_cases()[:9], ids=[c[0] for c in revised_cases()[:9]])
+def test_snapshot_trace_equals_python_restatement(oracle, name, case):
+    """CaptureSnapshot (:294-387) as numbers: the C oracle's trace and the Python restatement's
+    captures agree bit for bit, snapshot by snapshot (post-pivot y / rc / x_B, pre-pivot direction,
+    ratios and basis, Z_working, Z_original, B^-1 A by MultiplyMatrices :360, B^-1)."""
+    obj, cons, is_min = case
+    A, b = flat(cons)
+    tr = oracle.revised_trace(obj, A, b, is_min, max_iter=60, cap=64)
+    p = PyRevised(obj, cons, is_min)
+    ps = p.solve(max_iter=60, capture=True)
+    assert ps == STATUS[tr["status"]]
+    assert tr["count"] == len(p.snapshots) == len(tr["snapshots"])
+    for k, (a, q) in enumerate(zip(tr["snapshots"], p.snapshots)):
+        for key in ("entering", "leaving_row", "leaving_var"):
+            assert a[key] == q[key], (k, key)
+        for key in ("rc_pre", "z_working", "z_original"):
+            assert bits(a[key]) == bits(q[key]), (k, key)
+        for key in SNAP_KEYS:
+            assert a[key].tobytes() == np.array(q[key], dtype=np.float64).tobytes(), (k, key)
+        assert a["basis_pre"].tolist() == q["basis_pre"] and a["basis_post"].tolist() == q["basis_post"]
+        assert a["BInvA"].tobytes() == np.array(q["BInvA"]).tobytes(), k
+        assert a["BInv"].tobytes() == np.array(q["BInv"]).tobytes(), k
+
+
+def test_snapshot_text_of_the_sample_model():
+    """The text block of the last two snapshots of data/TextFile.txt through option 2 (what
+    Program.cs:336-337 prints): spot values worked out by hand from the SURVEY trace."""
+    obj, cons, is_min = sample_option2()
+    p = PyRevised(obj, cons, is_min)
+    assert p.solve(capture=True) == "optimal"
+    assert [s["title"] for s in p.snapshots] == [f"Iteration {k}" for k in range(1, 7)] + ["Optimal"]
+    last = py_snapshot_text(p.snapshots[-1], p.n, p.m, is_min)
+    assert last.startswith("Optimal\r\nCurrent Tableau (Revised Simplex)\r\nProblem type: MAX\r\n")
+    assert "Entering variable" not in last and "Ratio test" not in last
+    assert "Original objective Z_original (MAX): 15.4\r\n" in last
+    assert "Working objective Z_working (maxified): 15.4\r\n" in last
+    first = py_snapshot_text(p.snapshots[0], p.n, p.m, is_min)
+    # c = (2, 3, 3, 5, 2, 4): x4 enters with reduced cost 5; ratios 40/14 = 2.857 (S1), 1/1 (S5)
+    assert "Entering variable (chosen pre-pivot): x4  (reduced cost pre = 5)" in first
+    assert "Pivot (pre\u2192post): S5  \u2192  x4    (pivot = 1)" in first
+    assert "S1: 2.857\r\n" in first and "S2: \u221e\r\n" in first and "S5: 1\r\n" in first
+    assert "S1\t11\t8\t6\t0\t10\t10\t1\t0\t0\t0\t-14\t0\t0\t26\r\n" in first
+    assert first.rstrip("\r\n").endswith("Basic Variables: S1, S2, S3, S4, x4, S6, S7")
+
+
+def test_n3_restatement_against_the_host_formatter():
+    """Two independent restatements of NumFormat.N3 (:451-466) -- tests/ref_py.py (decimal module)
+    and the product's table_iteration_formater.N3 -- agree on ties, negatives, integers, tiny and
+    huge values."""
+    from lpr_381_group_v22_amd.table_iteration_formater import N3
+    rng = np.random.RandomState(3)
+    vals = [0.0, -0.0, 1e-13, -1e-13, 0.0005, -0.0005, 0.0015, 0.0025, 1.0005, 2.5, -2.5, 0.125,
+            0.0625, 15.399999999999999, 0.19999999999999973, 1e15, -1e15, 123456.7895, 1 / 3,
+            2 / 3, -1 / 3, 0.9995, 0.99949999, 1e-3, 9.9995, 1234567.0005]
+    vals += list(rng.randn(300)) + list(rng.randn(100) * 1e4) + \
+        [round(v, 3) + 0.0005 for v in rng.randn(100)]
+    for v in vals:
+        assert py_n3(v) == N3(v), repr(v)
