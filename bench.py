@@ -340,6 +340,10 @@ def bb_instance(nvars: int, ncons: int, seed: int):
 
 
 def run_bb(args, D: Dist):
+    """BASELINE configs[3]: level-synchronous Branch & Bound inside the library
+    (lpr_bb_solve_level_sync), sub-trees sharded over the ranks, ONE ncclAllReduce(MAX) of the
+    incumbent per level issued by the library on RCCL.  torch.distributed only carries the RCCL
+    unique id to the ranks and the bench's own barriers."""
     import numpy as np
     import lpr_381_group_v22_amd as pkg
     from lpr_381_group_v22_amd import Constraint
@@ -354,20 +358,41 @@ def run_bb(args, D: Dist):
         cons.append(Constraint(co, "<=", 1.0))
     primal = pkg.PrimalSimplexSolver(c.tolist(), cons, True, engine=eng, snapshots="none")
     primal.Solve()
+    R0, C0 = primal.tableau.rows, primal.tableau.cols
     tree = pkg.BranchBoundTree.from_tableau(primal.tableau, nv, max_depth=levels + 2)
+    comm = None
     if D.dist is not None:
-        arm, gather = pkg.torch_collectives()
-    else:
-        arm, gather = None, None
+        ids = [pkg.Comm.unique_id() if D.rank == 0 else None]
+        D.dist.broadcast_object_list(ids, src=0)
+        comm = pkg.Comm.rccl(eng, D.rank, D.world, ids[0])
     D.barrier(eng)
     t0 = time.perf_counter()
-    res = pkg.solve_level_synchronous(tree, nv, rank=D.rank, world=D.world, all_reduce_max=arm,
-                                      gather=gather, max_levels=levels)
+    res = pkg.solve_level_sync_native(tree, comm, max_levels=levels)
     D.barrier(eng)
     dt = time.perf_counter() - t0
     dt_max = D.max(dt)
     out = None
     if D.rank == 0:
+        # a child at depth d is (R0 + d) x (C0 + d); its pivot reads and writes it once (the C#
+        # builds a fresh tableau per pivot, :257-271).  Depths are not tracked per pivot: the
+        # mid-depth size stands for all of them (+-%d rows on %d)
+        Rm, Cm = R0 + levels / 2.0, C0 + levels / 2.0
+        bytes_per_pivot = 2 * 8 * Rm * Cm
+        achieved = res["pivots"] * bytes_per_pivot / dt_max / 1e9
+        cpu = None
+        if D.world == 1 and args.cpu_pivots != 0:
+            orc = _oracle()
+            T = primal.tableau.read()
+            c0 = time.perf_counter()
+            cap = 24
+            ref = orc.bb_solve(T, nv, node_cap=cap, rec_cap=1 << 12, piv_cap=1 << 20)
+            cdt = time.perf_counter() - c0
+            cpiv = sum(1 for t in ref["trace"] if t[1] < 2)
+            cpu = {"value": round(cpiv / cdt, 2), "unit": "pivots/s", "cores": 1, "kind": "port",
+                   "sample": f"the reference's DFS (BranchBoundSimplexSolver.cs:1006-1233) from "
+                             f"the same root, first {ref['processed']} nodes popped ({cpiv} "
+                             f"sub-problem pivots), C oracle, 1 thread; cpu: {_cpu_model()}",
+                   "nodes_per_s": round(ref["processed"] / cdt, 2)}
         out = {
             "metric": "Branch&Bound sub-problem pivots/sec (level-synchronous, sub-trees sharded)",
             "value": round(res["pivots"] / dt_max, 2), "unit": "pivots/s", "n_gpus": D.world,
@@ -376,14 +401,28 @@ def run_bb(args, D: Dist):
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"binary programme {nv} vars, {nc}+{nv} rows (root tableau "
-                                   f"{nc + nv + 1}x{2 * nv + nc + 1}), {levels} levels, "
-                                   f"pruning off, cap lifted",
+                                   f"{R0}x{C0}), {levels} levels, pruning off, cap lifted; "
+                                   f"a step = one level (all children of the frontier in one "
+                                   f"batch + one all-reduce)",
                        "nodes_processed": res["processed"], "pivots": res["pivots"],
                        "nodes_per_s": round(res["processed"] / dt_max, 1),
-                       "incumbent_z": res["z"] if res["found"] else None, "collective": "1 all-reduce(MAX, 16 B)/level",
+                       "incumbent_z": res["z"] if res["found"] else None,
+                       "collective": "1 ncclAllReduce(MAX, 24 B)/level issued by "
+                                     "lpr_bb_solve_level_sync" if comm else "none (one rank)",
                        "parallelism": f"subtree{D.world}"},
-            "roofline": None, "cpu_baseline": None,
+            "roofline": {"bound": "hbm", "kernel": "k_bb_update (batched out-of-place pivot of "
+                                                   "all live children)",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "bytes_per_pivot": int(bytes_per_pivot),
+                         "note": "whole-job form: bytes of all sub-problem pivots / wall time "
+                                 "(child set-up, selection kernels, host polls included); a child "
+                                 "tableau is ~%.1f MB, %d live children at the widest level stay "
+                                 "out of L2" % (Rm * Cm * 8 / 1e6, 1 << (levels - 1))},
+            "cpu_baseline": cpu,
         }
+    if comm is not None:
+        comm.destroy()
     tree.destroy()
     eng.close()
     return out

@@ -356,6 +356,63 @@ int lpr_bb_expand(lpr_bb* b, int count, const int32_t* parent_ids, const int32_t
 int lpr_bb_release(lpr_bb* b, const int32_t* ids, int count);
 int lpr_bb_node_read(lpr_bb* b, int32_t id, double* out, int32_t* rows, int32_t* cols);
 
+/* ---- multi-GPU Branch & Bound: one process per GPU, sub-trees sharded over the ranks, ONE
+ * all-reduce(MAX) of the incumbent bound per level over RCCL / xGMI.  The reference
+ * loop being sharded is ExecuteBranchAndBound (BranchBoundSimplexSolver.cs:1006-1233) with its
+ * 20-node stop lifted; with pruning off (Program.cs:389) the explored tree, and so the answer,
+ * does not depend on the number of ranks. */
+typedef struct lpr_comm lpr_comm;
+#define LPR_COMM_ID_BYTES 128
+/* Rank 0 makes the id (ncclGetUniqueId) and hands the 128 bytes to the other ranks by whatever
+ * channel the host has (a file, a socket, its launcher's environment); then every rank calls
+ * lpr_comm_init with its engine (= its GPU): ncclCommInitRank. */
+int lpr_comm_unique_id(uint8_t id[LPR_COMM_ID_BYTES]);
+int lpr_comm_init(lpr_engine* e, int rank, int world, const uint8_t id[LPR_COMM_ID_BYTES],
+                  lpr_comm** out);
+/* The same with the caller's own transport instead of RCCL.  Both callbacks return 0 on success
+ * and are invoked on the calling thread only: all_reduce_max(user, v, n) leaves in v[0..n) the
+ * element-wise maximum over all ranks; all_gather(user, send, recv, bytes) leaves in
+ * recv[world * bytes] the `bytes` of every rank in rank order. */
+typedef int (*lpr_allreduce_max_fn)(void* user, double* inout, int count);
+typedef int (*lpr_allgather_fn)(void* user, const void* send, void* recv, int bytes);
+int lpr_comm_init_custom(int rank, int world, lpr_allreduce_max_fn all_reduce_max,
+                         lpr_allgather_fn all_gather, void* user, lpr_comm** out);
+int lpr_comm_destroy(lpr_comm* c);
+/* rank, world and how many collectives this communicator has issued so far */
+int lpr_comm_info(const lpr_comm* c, int* rank, int* world, int64_t* allreduce_calls,
+                  int64_t* allgather_calls);
+/* inout[0..count) <- maximum over all ranks (count <= 64); the collective the B&B levels use */
+int lpr_comm_all_reduce_max(lpr_comm* c, double* inout, int count);
+
+typedef struct lpr_bb_sync_opts {
+    int32_t enable_pruning;  /* ShouldPrunebranch (:985-1004) against the all-reduced bound */
+    int32_t max_levels;      /* <= 0: max_depth of the handle */
+    int64_t max_nodes;       /* stop once a rank has processed more than this (<= 0: 2^20) */
+} lpr_bb_sync_opts;
+
+typedef struct lpr_bb_sync_result {
+    int32_t status;      /* LPR_OK_OPTIMAL, or LPR_BB_NODE_CAP when max_nodes stopped it */
+    int32_t found;       /* 0: no integer solution */
+    int64_t processed;   /* nodes scored, all ranks */
+    int64_t pivots;      /* dual + primal pivots of all child LPs, all ranks */
+    int32_t levels;      /* levels done = all-reduces issued */
+    int32_t path_len;    /* the winner's branch path: path_len sides from the root ... */
+    uint64_t path_bits;  /* ... bit k = side taken at depth k (0 lower "<= floor", 1 upper) */
+    double z;            /* incumbent objective (rounded to 4 decimals like every B&B value) */
+} lpr_bb_sync_result;
+
+/* Level-synchronous form of ExecuteBranchAndBound (:1006-1233): every level scores this rank's
+ * frontier (IsInteger :595-599, CheckIntegerBasicVar :829-847), branches (CreateBranches
+ * :859-890), evaluates ALL children in one batch (AddConstraint + DoDualSimplex on the device)
+ * and issues ONE all-reduce(MAX) of {incumbent z, "someone has nodes left", "someone hit
+ * max_nodes"}.  The first ceil(log2(world)) levels are done by every rank alike; the frontier at
+ * that depth is dealt round robin in DFS order and a sub-tree then stays on its rank -- tableaux
+ * never move.  Ties on z go to the node the reference's stack pops first.  One all-gather at the
+ * end names the winner.  comm == NULL: a single rank.  Every rank passes a handle holding the
+ * same root; x (nvars) is written on every rank when found. */
+int lpr_bb_solve_level_sync(lpr_bb* b, lpr_comm* comm, const lpr_bb_sync_opts* opts, double* x,
+                            lpr_bb_sync_result* res);
+
 /* ------------------------------------------------------------------------------------------
  * Sensitivity re-solve ("next" row f4): SensitivityAnalysis/SensitivityAnalyzer.cs.
  * The analyzer owns a device copy of the final tableau (the C# clones it, :24).  The console

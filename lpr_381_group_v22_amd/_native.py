@@ -93,6 +93,32 @@ class BBOpts(C.Structure):
     ]
 
 
+class BBSyncOpts(C.Structure):
+    _fields_ = [
+        ("enable_pruning", C.c_int32),
+        ("max_levels", C.c_int32),
+        ("max_nodes", C.c_int64),
+    ]
+
+
+class BBSyncResult(C.Structure):
+    _fields_ = [
+        ("status", C.c_int32),
+        ("found", C.c_int32),
+        ("processed", C.c_int64),
+        ("pivots", C.c_int64),
+        ("levels", C.c_int32),
+        ("path_len", C.c_int32),
+        ("path_bits", C.c_uint64),
+        ("z", C.c_double),
+    ]
+
+
+ALLREDUCE_MAX_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int)
+LPR_COMM_ID_BYTES = 128
+
+
 class BBResult(C.Structure):
     _fields_ = [
         ("status", C.c_int32),
@@ -169,6 +195,15 @@ SIGNATURES = {
     "lpr_bb_expand": (C.c_int, [_P, C.c_int, _I32, _I32, _D, _I32, _I32, _I32, _I32]),
     "lpr_bb_release": (C.c_int, [_P, _I32, C.c_int]),
     "lpr_bb_node_read": (C.c_int, [_P, C.c_int32, _D, _I32, _I32]),
+    "lpr_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
+    "lpr_comm_init": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_uint8), _PP]),
+    "lpr_comm_init_custom": (C.c_int, [C.c_int, C.c_int, ALLREDUCE_MAX_FN, ALLGATHER_FN,
+                                       C.c_void_p, _PP]),
+    "lpr_comm_destroy": (C.c_int, [_P]),
+    "lpr_comm_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), _I64, _I64]),
+    "lpr_comm_all_reduce_max": (C.c_int, [_P, _D, C.c_int]),
+    "lpr_bb_solve_level_sync": (C.c_int, [_P, _P, C.POINTER(BBSyncOpts), _D,
+                                          C.POINTER(BBSyncResult)]),
     "lpr_sens_create": (C.c_int, [_P, _D, C.c_int32, C.c_int32, _D, C.c_int32, C.c_double, _PP]),
     "lpr_sens_create_from_tableau": (C.c_int, [_P, C.c_int32, _PP]),
     "lpr_sens_destroy": (C.c_int, [_P]),

@@ -254,14 +254,17 @@ def solve_level_synchronous(evaluator, nvars: int, *, rank: int = 0, world: int 
     root -- sub-problems are independent LPs, nothing but the incumbent crosses xGMI.
 
     Per level: each rank scores its frontier nodes, updates its local incumbent, branches, and
-    evaluates all its children in ONE batched ``expand``; then ONE ``all_reduce(MAX)`` carrying the
-    incumbent objective (and, packed in the same call, whether any rank still has work).  With
+    evaluates all its children in ONE batched ``expand``; then ONE ``all_reduce(MAX)`` of three
+    doubles: the incumbent objective, "some rank still has nodes", "some rank passed max_nodes" --
+    so every rank leaves the loop on the same level.  ``all_reduce_max`` takes and returns a list.
+    (This is the Python mirror of ``lpr_bb_solve_level_sync`` -- the C ABI form, which calls RCCL
+    itself -- kept for the CPU tests with a stand-in evaluator.)  With
     pruning off (the reference's setting, Program.cs:389) the explored tree does not depend on the
     rank count, and ties on z go to the node the reference's stack pops first (lower child before
     upper child, parent before child), so the answer equals ExecuteBranchAndBound without its
     20-node cap.  Returns dict(x, z, found, processed, pivots, levels, path), same on all ranks."""
     if all_reduce_max is None:
-        all_reduce_max = lambda v: v  # noqa: E731
+        all_reduce_max = lambda v: list(v)  # noqa: E731  (takes and returns a 3-list)
     if gather is None:
         gather = lambda obj: [obj]  # noqa: E731
     split_level = 0
@@ -327,8 +330,10 @@ def solve_level_synchronous(evaluator, nvars: int, *, rank: int = 0, world: int 
         frontier = new_frontier
         # ---- the single collective of the level (RCCL all-reduce over xGMI): the incumbent
         # bound; "someone still has nodes" rides in the same MAX as a large offset-free flag ----
-        global_bound, busy = _reduce_bound_and_busy(all_reduce_max, best_z, bool(frontier))
-        if not busy or processed > max_nodes:
+        red = all_reduce_max([best_z, 1.0 if frontier else 0.0,
+                              1.0 if processed > max_nodes else 0.0])
+        global_bound, busy, capped = float(red[0]), red[1] > 0.5, red[2] > 0.5
+        if not busy or capped:  # decided from the same reduced values on every rank
             break
     if frontier:
         evaluator.release([nid for nid, _ in frontier])
@@ -347,16 +352,6 @@ def solve_level_synchronous(evaluator, nvars: int, *, rank: int = 0, world: int 
                 pivots=total_pivots, levels=levels, path=best[1])
 
 
-def _reduce_bound_and_busy(all_reduce_max, best_z: float, busy: bool):
-    """One MAX all-reduce of a 2-vector (bound, busy flag).  ``all_reduce_max`` may take a float
-    (tests) or a 2-list; both are supported so that the production path issues ONE collective."""
-    try:
-        out = all_reduce_max([best_z, 1.0 if busy else 0.0])
-        return float(out[0]), bool(out[1] > 0.5)
-    except TypeError:
-        return float(all_reduce_max(best_z)), bool(all_reduce_max(1.0 if busy else 0.0) > 0.5)
-
-
 def _dfs_before(a: Tuple[int, ...], b: Tuple[int, ...]) -> bool:
     """True if node `a` is popped before node `b` by the reference's stack (pre-order, lower
     child first): lexicographic order on the branch paths, a prefix (ancestor) first."""
@@ -372,11 +367,9 @@ def torch_collectives(group=None):
     dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
 
     def all_reduce_max(v):
-        t = torch.tensor(v if isinstance(v, (list, tuple)) else [v], dtype=torch.float64,
-                         device=dev)
+        t = torch.tensor(list(v), dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
-        out = t.cpu().tolist()
-        return out if isinstance(v, (list, tuple)) else out[0]
+        return t.cpu().tolist()
 
     def gather(obj):
         out = [None] * dist.get_world_size(group)
@@ -384,3 +377,96 @@ def torch_collectives(group=None):
         return out
 
     return all_reduce_max, gather
+
+
+class Comm:
+    """lpr_comm: the multi-GPU communicator of the C ABI.  ``Comm.rccl`` calls RCCL
+    (ncclCommInitRank) inside the library; ``Comm.custom`` plugs two Python callables (tests over
+    gloo).  The Branch & Bound levels issue ONE all-reduce(MAX) each through it."""
+
+    def __init__(self, handle, keep=()):
+        self._h = handle
+        self._keep = keep  # ctypes callbacks must outlive the handle
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_uint8 * N.LPR_COMM_ID_BYTES)()
+        N.check(N.lib.lpr_comm_unique_id(buf), "lpr_comm_unique_id")
+        return bytes(buf)
+
+    @classmethod
+    def rccl(cls, engine: Engine, rank: int, world: int, unique_id: bytes) -> "Comm":
+        buf = (C.c_uint8 * N.LPR_COMM_ID_BYTES).from_buffer_copy(unique_id)
+        h = C.c_void_p()
+        N.check(N.lib.lpr_comm_init(engine._h, rank, world, buf, C.byref(h)), "lpr_comm_init")
+        return cls(h)
+
+    @classmethod
+    def custom(cls, rank: int, world: int, all_reduce_max: Callable, all_gather: Callable) -> "Comm":
+        """all_reduce_max(list[float]) -> list[float]; all_gather(bytes) -> list[bytes] (by rank)."""
+        def _ar(_user, ptr, count):
+            try:
+                out = all_reduce_max([ptr[i] for i in range(count)])
+                for i in range(count):
+                    ptr[i] = out[i]
+                return 0
+            except Exception:  # never unwind through the C frames
+                return 1
+
+        def _ag(_user, send, recv, nbytes):
+            try:
+                parts = all_gather(C.string_at(send, nbytes))
+                C.memmove(recv, b"".join(parts), nbytes * len(parts))
+                return 0
+            except Exception:
+                return 1
+
+        ar, ag = N.ALLREDUCE_MAX_FN(_ar), N.ALLGATHER_FN(_ag)
+        h = C.c_void_p()
+        N.check(N.lib.lpr_comm_init_custom(rank, world, ar, ag, None, C.byref(h)),
+                "lpr_comm_init_custom")
+        return cls(h, keep=(ar, ag))
+
+    def info(self):
+        r, w = C.c_int(), C.c_int()
+        a, g = C.c_int64(), C.c_int64()
+        N.check(N.lib.lpr_comm_info(self._h, C.byref(r), C.byref(w), C.byref(a), C.byref(g)),
+                "lpr_comm_info")
+        return dict(rank=r.value, world=w.value, allreduce_calls=a.value, allgather_calls=g.value)
+
+    def all_reduce_max(self, values: Sequence[float]) -> List[float]:
+        buf = (C.c_double * len(values))(*values)
+        N.check(N.lib.lpr_comm_all_reduce_max(self._h, buf, len(values)),
+                "lpr_comm_all_reduce_max")
+        return list(buf)
+
+    def destroy(self):
+        if self._h:
+            N.lib.lpr_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+def solve_level_sync_native(tree: "BranchBoundTree", comm: Optional[Comm] = None, *,
+                            enable_pruning: bool = False, max_levels: int = 0,
+                            max_nodes: int = 0):
+    """lpr_bb_solve_level_sync: the level-synchronous multi-rank Branch & Bound inside the library
+    (its collectives are RCCL calls made by the library itself).  Same dict as
+    solve_level_synchronous."""
+    opts = N.BBSyncOpts(enable_pruning=1 if enable_pruning else 0, max_levels=max_levels,
+                        max_nodes=max_nodes)
+    res = N.BBSyncResult()
+    x = np.zeros(max(tree.nvars, 1), dtype=np.float64)
+    N.check(N.lib.lpr_bb_solve_level_sync(tree._h, comm._h if comm else None, C.byref(opts),
+                                          x.ctypes.data_as(C.POINTER(C.c_double)),
+                                          C.byref(res)), "lpr_bb_solve_level_sync")
+    path = tuple((res.path_bits >> k) & 1 for k in range(res.path_len)) if res.found else None
+    return dict(x=[float(v) for v in x[:tree.nvars]] if res.found else None,
+                z=res.z if res.found else -math.inf, found=bool(res.found),
+                processed=int(res.processed), pivots=int(res.pivots), levels=int(res.levels),
+                path=path, status=int(res.status))

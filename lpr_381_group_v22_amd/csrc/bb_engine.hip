@@ -7,12 +7,20 @@
 // children that are evaluated together.  Node tableaux never leave HBM.  No CPU fallback.
 #include "bb_common.hpp"
 
+#include <algorithm>
+
 #include <cmath>
 #include <new>
 
 #pragma clang fp contract(off)
 
+struct lpr_comm;
 namespace lpr {
+// comm_engine.hip
+int comm_rank(const lpr_comm* c);
+int comm_world(const lpr_comm* c);
+int comm_all_reduce_max(lpr_comm* c, double* v, int n);
+int comm_all_gather(lpr_comm* c, const void* send, void* recv, int bytes);
 
 // bb_kernels.hip
 void bb_launch_copy_in(lpr_bb* b, const double* src, int src_ld, int rows, int cols, double* dst);
@@ -599,6 +607,206 @@ int lpr_bb_run(lpr_bb* b, const lpr_bb_opts* opts, double* x, lpr_bb_result* res
     res->pivots = b->total_pivots;
     res->nodes_created = (int64_t)b->records.size();
     return status;
+}
+
+// ---- level-synchronous, multi-rank form (comm_engine.hip holds the transport) ----------------
+
+namespace {
+
+// A node's branch path from the root: side k (0 lower, 1 upper) in bit k, `len` sides.  The
+// reference's stack pops in pre-order, lower child first: lexicographic order of the paths, an
+// ancestor before its descendants.
+struct Path {
+    uint64_t bits = 0;
+    int len = 0;
+};
+bool dfs_before(const Path& a, const Path& b) {
+    const int n = a.len < b.len ? a.len : b.len;
+    for (int k = 0; k < n; ++k) {
+        const int x = (int)((a.bits >> k) & 1u), y = (int)((b.bits >> k) & 1u);
+        if (x != y) return x < y;
+    }
+    return a.len < b.len;
+}
+struct Front {
+    int node;
+    Path path;
+};
+
+}  // namespace
+
+int lpr_bb_solve_level_sync(lpr_bb* b, lpr_comm* comm, const lpr_bb_sync_opts* opts, double* x,
+                            lpr_bb_sync_result* res) {
+    LPR_LIVE_BB(b);
+    if (!res) return LPR_BAD_ARGUMENT;
+    LPR_HIP(hipSetDevice(b->eng->device));
+    lpr_bb_sync_opts o;
+    std::memset(&o, 0, sizeof o);
+    if (opts) o = *opts;
+    const int n = b->nvars;
+    int max_levels = o.max_levels > 0 ? o.max_levels : b->max_depth;
+    if (max_levels > b->max_depth) max_levels = b->max_depth;  // node buffers are sized for it
+    if (max_levels > 64) max_levels = 64;                      // the path is a 64-bit word
+    const int64_t max_nodes = o.max_nodes > 0 ? o.max_nodes : ((int64_t)1 << 20);
+    if (b->nodes.empty() || !b->nodes[0].live) {
+        set_error("lpr_bb_solve_level_sync: the root node has been consumed; create a new handle");
+        return LPR_BAD_ARGUMENT;
+    }
+    const int rank = comm_rank(comm), world = comm_world(comm);
+    int split_level = 0;
+    while ((1 << split_level) < world) ++split_level;
+
+    std::vector<Front> frontier{{0, Path()}};
+    bool have_best = false;
+    double best_z_local = -INFINITY;
+    Path best_path;
+    std::vector<double> best_x((size_t)(n > 0 ? n : 1), 0.0);
+    double global_bound = -INFINITY;
+    int64_t processed = 0, pivots = 0;
+    int levels = 0;
+    bool capped = false;
+    std::vector<int32_t> ids, parents, var, kind, child, cst, cpiv;
+    std::vector<double> zs, vals, bound;
+    std::vector<Path> paths;
+
+    while (levels < max_levels) {
+        const bool replicated = levels < split_level;  // every rank is doing the same nodes
+        const bool count_here = !replicated || rank == 0;
+        parents.clear(); var.clear(); bound.clear(); kind.clear(); paths.clear();
+        if (!frontier.empty()) {
+            const int cnt = (int)frontier.size();
+            ids.resize(cnt);
+            for (int q = 0; q < cnt; ++q) ids[q] = frontier[q].node;
+            zs.assign(cnt, 0.0);
+            vals.assign((size_t)cnt * (n > 0 ? n : 1), 0.0);
+            int rc = bb_node_info(b, ids.data(), cnt, zs.data(), vals.data());
+            if (rc != LPR_OK_OPTIMAL) return rc;
+            for (int q = 0; q < cnt; ++q) {
+                const double* v = vals.data() + (size_t)q * n;
+                const double z = zs[q];
+                if (count_here) ++processed;
+                if (o.enable_pruning && global_bound > -INFINITY && z <= global_bound)
+                    continue;  // ShouldPrunebranch :995-1001 against the all-reduced bound
+                bool allInt = true;  // UpdateOptimalSolution :943-981
+                for (int i = 0; i < n; ++i)
+                    if (!is_integer(v[i])) { allInt = false; break; }
+                if (allInt && (!have_best || z > best_z_local ||
+                               (z == best_z_local && dfs_before(frontier[q].path, best_path)))) {
+                    have_best = true;
+                    best_z_local = z;
+                    best_path = frontier[q].path;
+                    for (int i = 0; i < n; ++i) best_x[i] = v[i];
+                }
+                int bestVar = -1;  // CheckIntegerBasicVar :829-847
+                double bestValue = 0, minDist = INFINITY;
+                for (int i = 0; i < n; ++i) {
+                    if (!is_integer(v[i])) {
+                        const double dist = std::fabs((v[i] - std::floor(v[i])) - 0.5);
+                        if (dist < minDist) {
+                            minDist = dist;
+                            bestVar = i;
+                            bestValue = v[i];
+                        }
+                    }
+                }
+                if (bestVar < 0) continue;  // an integer node has no children (:1070-1076)
+                for (int side = 0; side < 2; ++side) {  // CreateBranches :859-890
+                    parents.push_back(frontier[q].node);
+                    var.push_back(bestVar);
+                    bound.push_back((double)(int)(side == 0 ? std::floor(bestValue)
+                                                            : std::ceil(bestValue)));
+                    kind.push_back(side);
+                    Path p = frontier[q].path;
+                    if (side) p.bits |= (uint64_t)1 << p.len;
+                    p.len += 1;
+                    paths.push_back(p);
+                }
+            }
+        }
+        std::vector<Front> next;
+        if (!parents.empty()) {
+            const int cnt = (int)parents.size();
+            child.assign(cnt, -1);
+            cst.assign(cnt, 0);
+            cpiv.assign(cnt, 0);
+            int rc = bb_expand(b, cnt, parents.data(), var.data(), bound.data(), kind.data(),
+                               child.data(), cst.data(), cpiv.data(), nullptr, nullptr);
+            if (rc != LPR_OK_OPTIMAL) return rc;
+            for (int q = 0; q < cnt; ++q) {
+                if (count_here) pivots += cpiv[q];
+                if (cst[q] == kBBSolved) next.push_back({child[q], paths[q]});
+            }
+        }
+        for (const Front& f : frontier) bb_release_node(b, f.node);
+        ++levels;
+        if (levels == split_level && world > 1) {
+            // deal the frontier of this depth: identical on every rank, so nothing is exchanged
+            std::stable_sort(next.begin(), next.end(),
+                             [](const Front& a, const Front& c) { return dfs_before(a.path, c.path); });
+            std::vector<Front> keep;
+            for (size_t i = 0; i < next.size(); ++i) {
+                if ((int)(i % (size_t)world) == rank) keep.push_back(next[i]);
+                else bb_release_node(b, next[i].node);
+            }
+            next.swap(keep);
+        }
+        frontier.swap(next);
+        // ---- the single collective of the level: incumbent bound, "someone has nodes left",
+        //      "someone has hit max_nodes" -- all three decided by every rank from the same sums
+        double red[3] = {best_z_local, frontier.empty() ? 0.0 : 1.0,
+                         processed > max_nodes ? 1.0 : 0.0};
+        int rc = comm_all_reduce_max(comm, red, 3);
+        if (rc != LPR_OK_OPTIMAL) return rc;
+        global_bound = red[0];
+        if (red[2] > 0.5) capped = true;
+        if (red[1] < 0.5 || capped) break;
+    }
+    for (const Front& f : frontier) bb_release_node(b, f.node);
+
+    // winner identity: one gather at termination, ties by DFS order (:966 "first found wins")
+    const int nx = n > 0 ? n : 1;
+    const size_t rec_d = 6 + (size_t)nx;  // doubles per rank
+    std::vector<double> mine(rec_d, 0.0), all(rec_d * (size_t)world, 0.0);
+    mine[0] = have_best ? 1.0 : 0.0;
+    mine[1] = best_z_local;
+    std::memcpy(&mine[2], &best_path.bits, sizeof(uint64_t));
+    mine[3] = (double)best_path.len;
+    mine[4] = (double)processed;
+    mine[5] = (double)pivots;
+    for (int i = 0; i < n; ++i) mine[6 + i] = best_x[i];
+    int rc = comm_all_gather(comm, mine.data(), all.data(), (int)(rec_d * sizeof(double)));
+    if (rc != LPR_OK_OPTIMAL) return rc;
+    bool found = false;
+    double wz = -INFINITY;
+    Path wp;
+    int wr = -1;
+    int64_t tot_proc = 0, tot_piv = 0;
+    for (int r = 0; r < world; ++r) {
+        const double* rr = all.data() + rec_d * (size_t)r;
+        tot_proc += (int64_t)rr[4];
+        tot_piv += (int64_t)rr[5];
+        if (rr[0] < 0.5) continue;
+        Path p;
+        std::memcpy(&p.bits, &rr[2], sizeof(uint64_t));
+        p.len = (int)rr[3];
+        if (!found || rr[1] > wz || (rr[1] == wz && dfs_before(p, wp))) {
+            found = true;
+            wz = rr[1];
+            wp = p;
+            wr = r;
+        }
+    }
+    if (found && x)
+        for (int i = 0; i < n; ++i) x[i] = all[rec_d * (size_t)wr + 6 + i];
+    res->status = capped ? LPR_BB_NODE_CAP : LPR_OK_OPTIMAL;
+    res->found = found ? 1 : 0;
+    res->processed = tot_proc;
+    res->pivots = tot_piv;
+    res->levels = levels;
+    res->path_len = found ? wp.len : 0;
+    res->path_bits = found ? wp.bits : 0;
+    res->z = found ? wz : -INFINITY;
+    return res->status;
 }
 
 int lpr_bb_records_read(lpr_bb* b, int32_t* parent, int32_t* kind, int32_t* depth, int32_t* var,

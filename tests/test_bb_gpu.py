@@ -159,3 +159,128 @@ def test_larger_root_batched_children(engine, oracle):
     assert got["pop_order"] == ref["pop_order"] and got["records"] == ref["records"]
     assert got["trace"] == ref["trace"]
     assert bits(got["z"]) == bits(ref["z"])
+
+
+def _terminating_cases(oracle):
+    out = []
+    for name, (obj, cons) in bb_cases.all_bb_cases():
+        st, T, n = bb_cases.primal_final_tableau(oracle, obj, cons)
+        ref = oracle.bb_solve(T, n, node_cap=300, rec_cap=1 << 12, piv_cap=1 << 18)
+        if ref["status"] == 0:
+            out.append((name, T, n, ref))
+    return out
+
+
+def test_level_sync_in_the_library_equals_the_python_mirror_and_the_dfs(engine, oracle):
+    """lpr_bb_solve_level_sync (the C ABI form; a single rank needs no communicator) against the
+    Python mirror of the same driver and against the reference's DFS without its cap."""
+    from lpr_381_group_v22_amd import (BranchBoundTree, solve_level_sync_native,
+                                       solve_level_synchronous)
+    done = 0
+    for name, T, n, ref in _terminating_cases(oracle):
+        a = BranchBoundTree.from_array(engine, T, n, max_depth=64)
+        got = solve_level_sync_native(a)
+        a.destroy()
+        b = BranchBoundTree.from_array(engine, T, n, max_depth=64)
+        py = solve_level_synchronous(b, n)
+        b.destroy()
+        assert got["status"] == 0 and got["found"] == py["found"] == ref["found"], name
+        assert got["processed"] == py["processed"] == ref["processed"], name
+        assert got["pivots"] == py["pivots"] and got["levels"] == py["levels"], name
+        assert got["path"] == (tuple(py["path"]) if py["path"] is not None else None), name
+        if ref["found"]:
+            assert bits(got["z"]) == bits(py["z"]) == bits(ref["z"]), name
+            assert [bits(v) for v in got["x"]] == [bits(v) for v in ref["x"]], name
+        done += 1
+    assert done >= 3
+
+
+def test_rccl_communicator_of_one_rank(engine, oracle):
+    """lpr_comm_init -> ncclCommInitRank inside the library (world size 1: the pool gives one GPU);
+    the levels' all-reduce(MAX) and the final all-gather really go through RCCL: one all-reduce per
+    level, one all-gather per solve."""
+    from lpr_381_group_v22_amd import BranchBoundTree, Comm, solve_level_sync_native
+    comm = Comm.rccl(engine, 0, 1, Comm.unique_id())
+    assert comm.info() == dict(rank=0, world=1, allreduce_calls=0, allgather_calls=0)
+    assert comm.all_reduce_max([1.5, -2.0, float("-inf")]) == [1.5, -2.0, float("-inf")]
+    name, T, n, ref = _terminating_cases(oracle)[0]
+    tree = BranchBoundTree.from_array(engine, T, n, max_depth=64)
+    got = solve_level_sync_native(tree, comm)
+    tree.destroy()
+    info = comm.info()
+    assert info["allreduce_calls"] == 1 + got["levels"] and info["allgather_calls"] == 1
+    assert got["found"] == ref["found"] and got["processed"] == ref["processed"]
+    if ref["found"]:
+        assert bits(got["z"]) == bits(ref["z"])
+    comm.destroy()
+
+
+def _two_rank_worker(rank, world, port, case_name, out_dir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import lpr_381_group_v22_amd as pkg
+    from oracle_lib import Oracle
+    import bb_cases as cases
+    orc = Oracle()
+    obj, cons = dict(cases.all_bb_cases())[case_name]
+    st, T, n = cases.primal_final_tableau(orc, obj, cons)
+
+    def arm(v):
+        t = torch.tensor(v, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.tolist()
+
+    def gather(b):
+        out = [None] * world
+        dist.all_gather_object(out, b)
+        return out
+
+    eng = pkg.Engine(0)  # both ranks share the one GPU of the box
+    comm = pkg.Comm.custom(rank, world, arm, gather)
+    tree = pkg.BranchBoundTree.from_array(eng, T, n, max_depth=64)
+    res = pkg.solve_level_sync_native(tree, comm)
+    res["calls"] = comm.info()
+    tree.destroy()
+    comm.destroy()
+    eng.close()
+    with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
+        json.dump({k: (list(v) if isinstance(v, tuple) else v) for k, v in res.items()}, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_level_sync_two_ranks_through_the_abi(engine, oracle):
+    """Two processes (ranks) on the one GPU of the box, lpr_bb_solve_level_sync on each, the
+    collectives carried by a caller-supplied transport (gloo): the frontier of depth 1 is dealt,
+    sub-trees stay put, one all-reduce per level, same answer as one rank and as the DFS."""
+    import socket
+    import tempfile
+    import torch.multiprocessing as mp
+    from lpr_381_group_v22_amd import BranchBoundTree, solve_level_sync_native
+    name, T, n, ref = _terminating_cases(oracle)[0]
+    tree = BranchBoundTree.from_array(engine, T, n, max_depth=64)
+    one = solve_level_sync_native(tree)
+    tree.destroy()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_two_rank_worker, args=(2, port, name, d), nprocs=2, join=True)
+        res = [json.load(open(os.path.join(d, f"rank{r}.json"))) for r in range(2)]
+    for r in res:
+        assert r["found"] == one["found"] == ref["found"]
+        assert r["processed"] == one["processed"] == ref["processed"]
+        assert r["pivots"] == one["pivots"] and r["levels"] == one["levels"]
+        assert r["calls"]["allreduce_calls"] == r["levels"] and r["calls"]["allgather_calls"] == 1
+        if ref["found"]:
+            assert bits(r["z"]) == bits(one["z"]) == bits(ref["z"])
+            assert [bits(v) for v in r["x"]] == [bits(v) for v in ref["x"]]
+            assert tuple(r["path"]) == tuple(one["path"])
