@@ -22,6 +22,16 @@ for step in "$@"; do
     tests-bb) run tests_bb 900 python -m pytest tests/test_bb_gpu.py tests/test_configs_gpu.py -m gpu -x -q ;;
     bench-bb) run bench_bb 600 python bench.py --workload bb ;;
     bench-revised) run bench_revised 600 python bench.py --workload revised --steps 200 --warmup 16 ;;
+    bench-configs)
+      run bench_m512 300 python bench.py --m 512 --n 1024 --steps 2000 --warmup 200
+      run bench_m2048 300 python bench.py --m 2048 --n 2048 --steps 128 --warmup 16
+      run bench_block1 300 python bench.py --block 1 --steps 256 --warmup 32
+      run bench_sens 600 python bench.py --workload sens --steps 32 --warmup 2 ;;
+    profile-bb)
+      rm -rf gpurun_out/${tag}_bbkt
+      run prof_bb 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_bbkt -o kt -- python3 bench.py --workload bb --cpu-pivots 0
+      find gpurun_out/${tag}_bbkt -name "*kernel_stats*" -exec cp {} gpurun_out/${tag}_bb_kernel_stats.csv \;
+      find gpurun_out/${tag}_bbkt -name "*kernel_trace*" -delete ;;
     probe) run probe 600 python tools/r2_probe.py ;;
     probe-quick) run probe 300 python tools/r2_probe.py --quick ;;
     bench) run bench 600 python bench.py ; run bench_driver 600 python bench.py --gpus 1 --steps 20 --warmup 5 ;;
