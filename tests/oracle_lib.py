@@ -24,6 +24,12 @@ def _newest_src() -> float:
 
 
 def build_oracle() -> str:
+    # LPR_ORACLE_SANITIZE=1 (tests/test_sanitizers.py): the -fsanitize=address,undefined build
+    if os.environ.get("LPR_ORACLE_SANITIZE") == "1":
+        so = os.path.join(ORACLE_DIR, "_build", "liblpr_oracle_asan.so")
+        if not os.path.exists(so) or os.path.getmtime(so) < _newest_src():
+            subprocess.run(["make", "-C", ORACLE_DIR, "asan"], check=True, capture_output=True)
+        return so
     if not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < _newest_src():
         subprocess.run(["make", "-C", ORACLE_DIR], check=True, capture_output=True)
     return ORACLE_SO

@@ -311,3 +311,32 @@ def test_handles_outlive_their_engine_safely():
         h.destroy()
         h.destroy()  # idempotent on the Python side
     eng.close()
+
+
+def test_abi_argument_errors_are_statuses_not_crashes(engine):
+    """Bad arguments across the ABI come back as LPR_BAD_ARGUMENT with a message (never a crash,
+    never an exception across the boundary)."""
+    import ctypes as C
+    import lpr_381_group_v22_amd as pkg
+    from lpr_381_group_v22_amd import _native as N
+    lib = N.lib
+    BAD = N.LPR_BAD_ARGUMENT
+    h = C.c_void_p()
+    assert lib.lpr_engine_open(99, C.byref(h)) == BAD and b"out of range" in lib.lpr_last_error()
+    assert lib.lpr_tableau_synthetic(engine._h, 0, 5, 1, C.byref(h)) == BAD
+    assert lib.lpr_tableau_create(engine._h, 3, 4, None, None, C.byref(h)) == BAD
+    tab = pkg.Tableau.synthetic(engine, 6, 9, 0)
+    assert lib.lpr_primal_solve(tab._h, None, None) == BAD
+    assert lib.lpr_select_leaving(tab._h, 10 ** 6, C.byref(C.c_int32())) == BAD
+    assert lib.lpr_pivot(tab._h, 0, 0) == BAD                      # row 0 is the Z row
+    assert lib.lpr_tableau_read_block(tab._h, 0, 99, 0, 1, None) == BAD
+    assert lib.lpr_debug_head_stamps(tab._h, None, -1, None) == BAD
+    assert lib.lpr_tableau_destroy(None) == BAD
+    tab.destroy()
+    assert lib.lpr_revised_step(None, None) == BAD
+    assert lib.lpr_revised_create(engine._h, 0, 0, None, None, 0, None, 0, C.byref(h)) == BAD
+    assert lib.lpr_bb_solve_level_sync(None, None, None, None, None) == BAD
+    assert lib.lpr_comm_init(engine._h, 3, 2, (C.c_uint8 * 128)(), C.byref(h)) == BAD
+    assert lib.lpr_comm_init_custom(0, 0, N.ALLREDUCE_MAX_FN(), N.ALLGATHER_FN(), None,
+                                    C.byref(h)) == BAD
+    assert lib.lpr_comm_destroy(None) == BAD and lib.lpr_comm_all_reduce_max(None, None, 1) == BAD
