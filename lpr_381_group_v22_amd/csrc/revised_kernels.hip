@@ -39,17 +39,23 @@ constexpr int kGRP = 16;   // operands fetched from LDS one group ahead of the a
 constexpr int kRB = 16;    // rows per workgroup
 constexpr int kKC = 128;   // columns per chunk
 
+// Two products in ONE pass over M: lanes 0..15 walk the rows against v (x_B = B^-1 b), lanes
+// 16..31 of the same wave walk the same rows against v2 (u = B^-1 a_e) -- the second walk rides in
+// the SIMD lanes the first leaves idle, so B^-1 is read once per iteration for both (the C# calls
+// MultiplyMatrixVector twice, :89 and :150; the sums and their order are the same).  v2 is skipped
+// when there is no entering variable or it is a slack (u is then a column of B^-1, k_rev_gather).
 __global__ __launch_bounds__(256) void k_rev_rowsum(const double* __restrict__ M, int ld, int m,
                                                     const double* __restrict__ v,
                                                     double* __restrict__ out,
-                                                    const RevState* __restrict__ st,
-                                                    int skip_if_slack, int n) {
+                                                    const double* __restrict__ v2,
+                                                    double* __restrict__ out2,
+                                                    const RevState* __restrict__ st, int n) {
     // +2 doubles per row: rows stay 16-byte aligned and the 16 consumer lanes hit disjoint banks
     // (kGRP more so that the one-group-ahead prefetch of the last group stays inside the array)
     __shared__ __attribute__((aligned(16))) double sM[2][kRB][kKC + kGRP + 2];
-    __shared__ __attribute__((aligned(16))) double sv[2][kKC + kGRP];
+    __shared__ __attribute__((aligned(16))) double sv[2][2][kKC + kGRP];
     if (st->status != kRunning) return;
-    if (skip_if_slack && st->entering >= n) return;
+    const bool two = v2 != nullptr && st->entering >= 0 && st->entering < n;
     const int tid = threadIdx.x;
     const int row0 = blockIdx.x * kRB;
     const int nchunk = (m + kKC - 1) / kKC;
@@ -67,6 +73,7 @@ __global__ __launch_bounds__(256) void k_rev_rowsum(const double* __restrict__ M
                         : make_double2(0.0, 0.0);
         }
         if (tid < kKC) rv = (k0 + tid < m) ? v[k0 + tid] : 0.0;
+        else if (two && tid < 2 * kKC) rv = (k0 + tid - kKC < m) ? v2[k0 + tid - kKC] : 0.0;
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll
@@ -76,7 +83,8 @@ __global__ __launch_bounds__(256) void k_rev_rowsum(const double* __restrict__ M
             sM[buf][r][k] = rm[q].x;
             sM[buf][r][k + 1] = rm[q].y;
         }
-        if (tid < kKC) sv[buf][tid] = rv;
+        if (tid < kKC) sv[buf][0][tid] = rv;
+        else if (two && tid < 2 * kKC) sv[buf][1][tid - kKC] = rv;
     };
     load_chunk(0);
     store_chunk(0);
@@ -85,11 +93,11 @@ __global__ __launch_bounds__(256) void k_rev_rowsum(const double* __restrict__ M
     for (int c = 0; c < nchunk; ++c) {
         const int buf = c & 1;
         if (c + 1 < nchunk) load_chunk((c + 1) * kKC);  // in flight under the serial walk below
-        if (tid < kRB) {
+        if (tid < kRB || (two && tid < 2 * kRB)) {
             // the serial walk: the products are independent, only the adds form the chain
             const int kmax = min(kKC, m - c * kKC);
-            const double* __restrict__ row = sM[buf][tid];
-            const double* __restrict__ vv = sv[buf];
+            const double* __restrict__ row = sM[buf][tid & (kRB - 1)];
+            const double* __restrict__ vv = sv[buf][tid / kRB];
             if (kmax == kKC) {
                 double a[kGRP], b[kGRP];
 #pragma unroll
@@ -127,6 +135,7 @@ __global__ __launch_bounds__(256) void k_rev_rowsum(const double* __restrict__ M
         __syncthreads();
     }
     if (tid < kRB && row0 + tid < m) out[row0 + tid] = s;
+    if (two && tid >= kRB && tid < 2 * kRB && row0 + tid - kRB < m) out2[row0 + tid - kRB] = s;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -248,26 +257,15 @@ __device__ __forceinline__ int block_min_int(int v, int* lds) {
 // exactly by repeatedly searching, in parallel, for the FIRST index after the current one at
 // which the C# would replace its running best ("next take"), until there is none.  The number of
 // rounds is the number of replacements the sequential loop makes (O(log N) on random data).
-// Also performs the feasibility test `xB.Any(x => x < -EPS)` (:90-91) and the pivot-limit check.
 __global__ __launch_bounds__(1024) void k_rev_enter(const double* __restrict__ rcx,
                                                     const double* __restrict__ y,
-                                                    const double* __restrict__ xB,
                                                     const uint8_t* __restrict__ is_basic, int n,
                                                     int m, RevState* st) {
-    __shared__ int lds[16];
     if (st->status != kRunning) return;
     const int tid = threadIdx.x;
-    const int nt = blockDim.x;
-
-    int bad = INT_MAX;
-    for (int i = tid; i < m; i += nt)
-        if (xB[i] < -kEps) { bad = i; break; }
-    bad = block_min_int(bad, lds);
-    if (bad != INT_MAX) {
-        if (tid == 0) st->status = LPR_INFEASIBLE_BASIS;
-        return;
-    }
-
+    // (the feasibility test of :90-91, "optimal" and the pivot limit are decided in k_rev_ratio,
+    // once x_B -- computed together with u in one pass over B^-1 -- is there; the entering choice
+    // itself does not read x_B, and nothing is modified before those tests either way)
     const int N = n + m;
     // "rc > EPS, and first or rc > best + EPS" over ascending non-basic indices (:105-121; the
     // equal-within-EPS clause needs a smaller index than the current one and can never fire in
@@ -283,11 +281,7 @@ __global__ __launch_bounds__(1024) void k_rev_enter(const double* __restrict__ r
             return (rc > kEps) ? -rc : (double)NAN;
         },
         lds_i2, lds_v2);
-    if (tid == 0) {
-        st->entering = cur;
-        if (cur < 0) st->status = LPR_OK_OPTIMAL;  // :124-146
-        else if (st->max_iter > 0 && st->iter >= st->max_iter) st->status = LPR_PIVOT_LIMIT;
-    }
+    if (tid == 0) st->entering = cur;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -300,6 +294,7 @@ __global__ __launch_bounds__(256) void k_rev_gather(const double* __restrict__ A
                                                     const RevState* __restrict__ st) {
     if (st->status != kRunning) return;
     const int e = st->entering;
+    if (e < 0) return;  // no entering variable: k_rev_ratio will report the optimum
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
     if (e < n) acol[i] = A[(size_t)i * lda + e];
@@ -331,6 +326,22 @@ __global__ __launch_bounds__(1024) void k_rev_ratio(const double* __restrict__ u
     const int tid = threadIdx.x;
     const int nt = blockDim.x;
     const int e = st->entering;
+    {   // the loop head's exits, in the C#'s order: infeasible basis (:90-91), optimal (:124-146),
+        // then (no C# counterpart) the caller's pivot limit
+        int bad = INT_MAX;
+        for (int i = tid; i < m; i += nt)
+            if (xB[i] < -kEps) { bad = i; break; }
+        bad = block_min_int(bad, lds);
+        int32_t out = kRunning;
+        if (bad != INT_MAX) out = LPR_INFEASIBLE_BASIS;
+        else if (e < 0) out = LPR_OK_OPTIMAL;
+        else if (st->max_iter > 0 && st->iter >= st->max_iter) out = LPR_PIVOT_LIMIT;
+        __syncthreads();  // every lane has read the state before lane 0 changes it
+        if (out != kRunning) {
+            if (tid == 0) st->status = out;
+            return;
+        }
+    }
 
     // Ratios and basic-variable indices of this lane's rows are computed ONCE into registers
     // (first kCacheR * 1024 rows; rows beyond are re-read): NaN marks "u_i <= EPS" (:161,:172-175).
@@ -524,7 +535,7 @@ __global__ __launch_bounds__(256) void k_rev_snap_pre(const double* __restrict__
                                                       int32_t* __restrict__ basis_pre,
                                                       double* __restrict__ scal,
                                                       const RevState* __restrict__ st) {
-    if (st->status != kRunning) return;
+    if (st->status != kRunning || st->entering < 0) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) {
         const int e = st->entering;
@@ -772,7 +783,7 @@ void rev_launch_prices(lpr_revised* s) {
     const int m = s->m, n = s->n;
     // x_B = B^-1 b (:89)
     hipLaunchKernelGGL(k_rev_rowsum, dim3((m + kRB - 1) / kRB), dim3(256), 0, st, s->Binv, s->ldb,
-                       m, s->b, s->xB, s->state, 0, n);
+                       m, s->b, s->xB, (const double*)nullptr, (double*)nullptr, s->state, n);
     // y = c_B B^-1 (:93)
     hipLaunchKernelGGL(k_rev_colsum, dim3((m + kCB - 1) / kCB), dim3(256), 0, st, s->Binv, s->ldb,
                        m, m, s->cB, (const double*)nullptr, s->y, 0, s->state);
@@ -796,14 +807,20 @@ void rev_launch_matmul_exact(lpr_revised* s, double* Cout, int ldc) {
 void rev_launch_iteration(lpr_revised* s, bool snapshot) {
     hipStream_t st = s->eng->stream;
     const int m = s->m, n = s->n;
-    rev_launch_prices(s);
-    hipLaunchKernelGGL(k_rev_enter, dim3(1), dim3(1024), 0, st, s->rcx, s->y, s->xB, s->is_basic,
-                       n, m, s->state);
+    // y = c_B B^-1 (:93)
+    hipLaunchKernelGGL(k_rev_colsum, dim3((m + kCB - 1) / kCB), dim3(256), 0, st, s->Binv, s->ldb,
+                       m, m, s->cB, (const double*)nullptr, s->y, 0, s->state);
+    // rc_j = c_j - y.A_j (:96-98)
+    hipLaunchKernelGGL(k_rev_colsum, dim3((n + kCB - 1) / kCB), dim3(256), 0, st, s->A, s->lda, m,
+                       n, s->y, s->c, s->rcx, 1, s->state);
+    hipLaunchKernelGGL(k_rev_enter, dim3(1), dim3(1024), 0, st, s->rcx, s->y, s->is_basic, n, m,
+                       s->state);
     hipLaunchKernelGGL(k_rev_gather, dim3((m + 255) / 256), dim3(256), 0, st, s->A, s->lda,
                        s->Binv, s->ldb, n, m, s->acol, s->u, s->state);
-    // u = B^-1 a_e (:150) unless the entering variable is a slack
+    // x_B = B^-1 b (:89) and u = B^-1 a_e (:150; unless the entering variable is a slack) in one
+    // pass over B^-1
     hipLaunchKernelGGL(k_rev_rowsum, dim3((m + kRB - 1) / kRB), dim3(256), 0, st, s->Binv, s->ldb,
-                       m, s->acol, s->u, s->state, 1, n);
+                       m, s->b, s->xB, s->acol, s->u, s->state, n);
     if (snapshot)
         hipLaunchKernelGGL(k_rev_snap_pre, dim3((m + 255) / 256), dim3(256), 0, st, s->u, s->xB,
                            s->basic, s->rcx, s->y, n, m, s->snap_ratios, s->snap_basis,

@@ -105,6 +105,15 @@ def test_config3_bb_hundreds_of_live_subproblems(engine, oracle):
     gpu_ev = Counting(tree)
     got = solve_level_synchronous(gpu_ev, n, max_levels=levels)
     tree.destroy()
+    # the same through the library's own driver (lpr_bb_solve_level_sync)
+    from lpr_381_group_v22_amd import solve_level_sync_native
+    tree2 = BranchBoundTree.from_array(engine, T, n, max_depth=levels + 2)
+    nat = solve_level_sync_native(tree2, max_levels=levels)
+    tree2.destroy()
+    assert (nat["processed"], nat["pivots"], nat["levels"], nat["found"]) == \
+        (got["processed"], got["pivots"], got["levels"], got["found"])
+    assert bits(nat["z"]) == bits(got["z"]) and nat["path"] == (
+        tuple(got["path"]) if got["path"] is not None else None)
     ref = solve_level_synchronous(OracleEvaluator(oracle, T, n), n, max_levels=levels)
     assert gpu_ev.max_batch >= 128, f"largest batch was only {gpu_ev.max_batch} children"
     assert got["processed"] == ref["processed"] and got["pivots"] == ref["pivots"]
