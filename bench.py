@@ -153,7 +153,9 @@ def run_primal(args, D: Dist):
         # timing (asking for it would switch to another path): whole-job figures only
         timed = False
     if W > 0:
-        res = tab.solve(max_pivots=W * B, time_kernels=False, variant=args.variant,
+        # warm-up in the timed region's own mode (the engine creates its HIP events on first use:
+        # ~10 us each, which is not pivot time); the statistics below are differences
+        res = tab.solve(max_pivots=W * B, time_kernels=timed, variant=args.variant,
                         block=args.block)
         if res.pivots != W * B:
             raise SystemExit(f"warm-up ended after {res.pivots} pivots (status {res.status})")

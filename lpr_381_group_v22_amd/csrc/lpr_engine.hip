@@ -539,8 +539,8 @@ static int solve_overlapped(lpr_tableau* t, const lpr_solve_opts& o, int K, int 
         }
         // One or two launches per K pivots: plain launches keep the device busy (measured: a
         // captured graph is no faster here, and capturing one costs milliseconds per solve call).
-        if (timed) {
-            while ((int)t->ev.size() < 2 * nb + 2) {
+        if (timed) {  // (sized for a full batch at once: creating an event costs ~10 us)
+            while ((int)t->ev.size() < 2 * (nb > nlaunch ? nb : nlaunch) + 2) {
                 hipEvent_t ev;
                 LPR_HIP(hipEventCreate(&ev));
                 t->ev.push_back(ev);
