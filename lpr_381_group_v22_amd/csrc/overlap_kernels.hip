@@ -1638,6 +1638,10 @@ int ov_set_log(lpr_tableau* t, int parity) {
     c->h_ctl[0].log_cap = t->log_cap;
     LPR_HIP(hipMemcpyAsync(&c->b.ctl[parity].log_cap, &c->h_ctl[0].log_cap, sizeof(int64_t),
                            hipMemcpyHostToDevice, t->eng->stream));
+    // the loop heads read this word from their OWN stream, which only waits for the engine
+    // stream's previous sweep: without this wait the first heads of the next batch could still
+    // see the old capacity and drop log entries (rare: the log doubles a handful of times a solve)
+    LPR_HIP(hipStreamSynchronize(t->eng->stream));
     return LPR_OK_OPTIMAL;
 }
 
