@@ -119,12 +119,13 @@ typedef struct lpr_solve_opts {
                               bits: path + sweep tile (0x30tr two-stream overlap, 0x40tr heads then
                               in-place sweep, 0x50tr one-launch overlap, 0x60tr one launch per head;
                               tr = 0x04/0x08/0x10 rows per chunk, 0x24/0x28 two chunks in flight).
-                              Bits 16..20, K-pivot paths: 0x10000 diagnostic time stamps of the loop
+                              Bits 16..21, K-pivot paths: 0x10000 diagnostic time stamps of the loop
                               heads, 0x20000 loop heads not confined to one XCD, 0x40000 confined
                               but hand-offs through the memory side, 0x80000 the sweep does not
                               leave the heads' XCD to them, 0x100000 it does so only once this
                               launch's heads have said where they are (no hint from the previous
-                              launch). */
+                              launch), 0x200000 the heads wait for the previous sweep by a
+                              cross-stream event instead of on the device. */
     int32_t block;         /* pivots decided ahead and applied per sweep of the tableau on large
                               tableaux: 0 auto (16), 1 one pivot per sweep, 2..16 that many.  The bits
                               stored are the same for every value (each element goes through the

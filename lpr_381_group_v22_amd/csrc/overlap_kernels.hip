@@ -66,6 +66,7 @@ struct OvBuffers {      // everything the step kernel touches, passed by value
     unsigned long long* xgran;  // [kOvGroups] {launch epoch, XCC id} of every head workgroup
     unsigned long long* hx;     // {launch epoch, 0x100 | XCC id}: the XCD this launch's heads share
     unsigned* tileq;            // [2] next tile of the sweep (work queue), by launch parity
+    unsigned* sflag;            // sweeps completed in this solve call (k_ov_flag behind each sweep)
     unsigned long long* dbg;    // diagnostic time stamps of the lead head workgroup (or null)
     OvCtl* ctl;         // [2]
     unsigned* bar;      // [2]
@@ -89,7 +90,8 @@ __global__ __launch_bounds__(1024) void k_ov_prologue(const double* __restrict__
                                                       unsigned long long* __restrict__ xgran,
                                                       unsigned* __restrict__ bar,
                                                       unsigned* __restrict__ tileq,
-                                                      unsigned long long* __restrict__ hx) {
+                                                      unsigned long long* __restrict__ hx,
+                                                      unsigned* __restrict__ sflag) {
     __shared__ double lds_v[16];
     __shared__ int lds_i[16];
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -99,6 +101,7 @@ __global__ __launch_bounds__(1024) void k_ov_prologue(const double* __restrict__
     if (tid < 4) bar[tid] = 0u;
     if (tid < 2) tileq[tid] = 0u;
     if (tid == 0) *hx = 0ull;
+    if (tid == 0) *sflag = 0u;
     __syncthreads();
     Cand c;
     c.v = 0.0;
@@ -652,9 +655,17 @@ __device__ __forceinline__ void ov_publish_min(Cand c, double* lds_v, int* lds_i
 // they are equal do the hand-offs of this launch go through that XCD's L2 (hst / gr_publish with
 // l2 = true); otherwise they take the memory-side form.  Same bits either way.
 // STAMP: diagnostic build, the lead workgroup leaves s_memrealtime stamps per phase in B.dbg.
+// wait_sweeps >= 0 (two-stream form): this launch was queued right behind the previous heads,
+// WITHOUT waiting for the sweep that writes the tableau buffer it reads; it does its start-up
+// (placement check, register fills from the staging slots) and then waits until B.sflag -- stored
+// by a one-lane kernel queued behind every sweep -- says that `wait_sweeps` sweeps of this solve
+// call have completed.  The cross-stream event that used to order the two (5-10 us of latency per
+// step, on the critical path whenever the heads end last) is gone.  In this form the heads also own
+// the control-block fields the sweep used to write (applied / cur / sweep parity): the sweep of the
+// same step only reads the control block.
 template <int NT, bool STAMP>
 __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, int K, int G, int lp,
-                              bool solo, int spread, int no_l2) {
+                              bool solo, int spread, int no_l2, int wait_sweeps) {
     if ((int)blockIdx.x % spread != 0) return;
     __shared__ double lds_v[16];
     __shared__ int lds_i[16];
@@ -769,6 +780,23 @@ __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, i
             if (lead && tid == 0 && l2 && !solo)
                 __hip_atomic_store(B.hx, ((unsigned long long)xepoch << 32) | 0x100u | my_xcc,
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (wait_sweeps > 0) {  // the tableau buffer this launch reads: has its sweep ended?
+                if (tid == 0) {
+                    int fail = 1;
+                    for (unsigned spins = 0; spins < kOvSpinMax; ++spins) {
+                        if (__hip_atomic_load(B.sflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >=
+                            (unsigned)wait_sweeps) {
+                            fail = 0;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    s_pick[1] = fail;
+                }
+                __syncthreads();
+                if (s_pick[1]) err = 1;
+                __syncthreads();
+            }
             if (STAMP && stamp) {
                 B.dbg[(size_t)kOvStampPivots * kOvStampsPerPivot + 0] = my_xcc;
                 B.dbg[(size_t)kOvStampPivots * kOvStampsPerPivot + 1] = l2 ? 1u : 0u;
@@ -1118,6 +1146,19 @@ __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, i
 
     if (lead && tid == 0) {  // the next launch's view (fields owned by the heads)
         const bool staged_now = (status == kRunning && pend_in == kRunning);
+        if (wait_sweeps > 0 && !staged_now) {
+            // a launch that stages nothing has not waited yet: the block written below is the
+            // one the sweep of the PREVIOUS step is still reading (kdone, r[], slot, ...)
+            unsigned spins = 0;
+            while (__hip_atomic_load(B.sflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <
+                   (unsigned)wait_sweeps) {
+                if (++spins > kOvSpinMax) {
+                    err = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
         co->status = err ? LPR_DEVICE_ERROR : status_out;
         co->pending = pend_out;
         co->kdone = staged_now ? count : 0;
@@ -1128,6 +1169,12 @@ __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, i
         co->error = err | ci->error;
         co->head_xcc = l2 ? (int)my_xcc : (staging ? -1 : ci->head_xcc);
         B.bar[lp ^ 1] = 0u;
+        if (wait_sweeps >= 0) {  // the fields of the sweep running beside this launch
+            const int ks = (status == kRunning) ? ci->kdone : 0;
+            co->applied = ci->applied + ks;
+            co->cur = (ks > 0) ? (ci->cur ^ 1) : ci->cur;
+            co->sweep = ci->sweep ^ 1;
+        }
         if (solo) {
             B.tileq[1] = 0u;  // the in-place sweep that follows always runs on control block 1
             co->applied = ci->applied;
@@ -1358,7 +1405,8 @@ __device__ __forceinline__ void ov_one_tile(const OvBuffers& B, const OvCtl* ci,
 template <int TR, bool DB, bool INPLACE>
 __device__ __forceinline__ void ov_tiles(const OvBuffers& B, const double* __restrict__ fcol,
                                          const double* __restrict__ prow, int ld, int R, int Rp,
-                                         int G, int lp, int static_tile, int avoid) {
+                                         int G, int lp, int static_tile, int avoid,
+                                         bool write_ctl = true) {
     static_assert(kOvTileRows % (2 * TR) == 0, "tile rows must be a multiple of two chunks");
     __shared__ int s_tile;
     const OvCtl* ci = B.ctl + lp;
@@ -1367,9 +1415,11 @@ __device__ __forceinline__ void ov_tiles(const OvBuffers& B, const double* __res
     const bool first_wg = ((int)blockIdx.x == G);
     if (first_wg && threadIdx.x == 0) {  // the next launch's view (fields owned by the sweep)
         OvCtl* co = B.ctl + (lp ^ 1);
-        co->applied = ci->applied + K;
-        co->cur = (K > 0 && !INPLACE) ? (cur ^ 1) : cur;
-        co->sweep = ci->sweep ^ 1;
+        if (write_ctl) {  // (the heads write these when they run ahead of the event, see there)
+            co->applied = ci->applied + K;
+            co->cur = (K > 0 && !INPLACE) ? (cur ^ 1) : cur;
+            co->sweep = ci->sweep ^ 1;
+        }
         B.tileq[lp ^ 1] = 0u;  // nobody touches the other queue during this launch
         if (INPLACE) {  // no heads in this launch: their fields are carried over here
             co->status = ci->status;
@@ -1441,16 +1491,24 @@ __global__ __launch_bounds__(kOvNT) void k_ov_step(const OvBuffers B,
 // registers cap the occupancy of the sweep's tiles and vice versa).
 template <int NT, bool STAMP>
 __global__ __launch_bounds__(NT) void k_ov2_heads(const OvBuffers B, int ld, int R, int C, int Rp,
-                                                  int K, int G, int lp, int spread, int no_l2) {
-    ov_heads_rich<NT, STAMP>(B, ld, R, C, Rp, K, G, lp, false, spread, no_l2);
+                                                  int K, int G, int lp, int spread, int no_l2,
+                                                  int wait_sweeps) {
+    ov_heads_rich<NT, STAMP>(B, ld, R, C, Rp, K, G, lp, false, spread, no_l2, wait_sweeps);
+}
+
+// queued behind every sweep of the two-stream form: "n sweeps of this solve call are complete"
+__global__ void k_ov_flag(unsigned* flag, unsigned n) {
+    if (threadIdx.x == 0 && blockIdx.x == 0)
+        __hip_atomic_store(flag, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <int TR, bool DB>
 __global__ __launch_bounds__(kOvNT) void k_ov2_sweep(const OvBuffers B,
                                                      const double* __restrict__ fcol_ro,
                                                      const double* __restrict__ prow_ro, int ld,
-                                                     int R, int Rp, int lp, int avoid) {
-    ov_tiles<TR, DB, false>(B, fcol_ro, prow_ro, ld, R, Rp, 0, lp, -1, avoid);
+                                                     int R, int Rp, int lp, int avoid,
+                                                     int write_ctl) {
+    ov_tiles<TR, DB, false>(B, fcol_ro, prow_ro, ld, R, Rp, 0, lp, -1, avoid, write_ctl != 0);
 }
 
 // The same two halves as separate launches: all K loop heads of a block in ONE persistent launch
@@ -1459,7 +1517,7 @@ __global__ __launch_bounds__(kOvNT) void k_ov2_sweep(const OvBuffers B,
 template <int NT, bool STAMP>
 __global__ __launch_bounds__(NT) void k_ov_heads(const OvBuffers B, int ld, int R, int C, int Rp,
                                                  int K, int G, int spread, int no_l2) {
-    ov_heads_rich<NT, STAMP>(B, ld, R, C, Rp, K, G, 0, true, spread, no_l2);
+    ov_heads_rich<NT, STAMP>(B, ld, R, C, Rp, K, G, 0, true, spread, no_l2, -1);
 }
 
 template <int TR, bool DB>
@@ -1486,6 +1544,7 @@ struct lpr_overlap_ctx {
     hipStream_t hstream = nullptr;  // the heads' stream of the two-stream variant
     hipEvent_t ev_h[2] = {nullptr, nullptr}, ev_s[2] = {nullptr, nullptr};
     int ev_idx = 0;
+    int steps = 0;                  // launch pairs queued by the current solve call
 };
 
 namespace lpr {
@@ -1520,6 +1579,7 @@ void ov_release(lpr_tableau* t) {
     hipFree(c->b.xgran);
     hipFree(c->b.hx);
     hipFree(c->b.tileq);
+    hipFree(c->b.sflag);
     hipFree(c->b.dbg);
     hipFree(c->b.ctl);
     hipFree(c->b.bar);
@@ -1555,6 +1615,7 @@ int ov_ensure(lpr_tableau* t, bool second_buffer) {
     chk(hipMalloc(&c->b.dbg, kOvDbgWords * sizeof(unsigned long long)));
     chk(hipMalloc(&c->b.hx, 2 * sizeof(unsigned long long)));
     chk(hipMalloc(&c->b.tileq, 4 * sizeof(unsigned)));
+    chk(hipMalloc(&c->b.sflag, 4 * sizeof(unsigned)));
     chk(hipMalloc(&c->b.ctl, 2 * sizeof(OvCtl)));
     chk(hipMalloc(&c->b.bar, 4 * sizeof(unsigned)));
     chk(hipHostMalloc(&c->h_ctl, 2 * sizeof(OvCtl)));
@@ -1626,7 +1687,7 @@ int ov_begin(lpr_tableau* t, int64_t iter, int64_t max_iter) {
                        c->b.zrow, c->b.bvec + (size_t)(iter & 1) * c->Rp,
                        c->b.zparts + (iter & 1) * kOvGroups, ov_groups(t),
                        c->b.gran + (size_t)(iter & 1) * 3 * kOvGroups, (unsigned)(2 * iter + 1),
-                       c->b.gran, c->b.xgran, c->b.bar, c->b.tileq, c->b.hx);
+                       c->b.gran, c->b.xgran, c->b.bar, c->b.tileq, c->b.hx, c->b.sflag);
     LPR_HIP(hipGetLastError());
     return LPR_OK_OPTIMAL;
 }
@@ -1713,8 +1774,10 @@ int ov2_begin(lpr_tableau* t) {
     }
     // everything queued on the engine stream so far (prologue, control block) precedes step 0
     c->ev_idx = 0;
+    c->steps = 0;
     LPR_HIP(hipEventRecord(c->ev_s[1], t->eng->stream));
     LPR_HIP(hipEventRecord(c->ev_h[1], c->hstream));
+    LPR_HIP(hipStreamWaitEvent(c->hstream, c->ev_s[1], 0));
     return LPR_OK_OPTIMAL;
 }
 
@@ -1723,7 +1786,11 @@ int ov2_launch_step(lpr_tableau* t, int K, int tr, int lp, int flags, hipEvent_t
     lpr_overlap_ctx* c = static_cast<lpr_overlap_ctx*>(t->ov);
     hipStream_t S = t->eng->stream, H = c->hstream;
     const int cur = c->ev_idx, prev = cur ^ 1;
-    LPR_HIP(hipStreamWaitEvent(H, c->ev_s[prev], 0));
+    // flags 32: the round-1 hand-over (the heads wait for the previous sweep by a cross-stream
+    // event); default: the heads follow their predecessor at once and wait on the device (B.sflag)
+    const bool by_event = (flags & 32) != 0;
+    const int wait_sweeps = by_event ? -1 : c->steps;
+    if (by_event) LPR_HIP(hipStreamWaitEvent(H, c->ev_s[prev], 0));
     LPR_HIP(hipStreamWaitEvent(S, c->ev_h[prev], 0));
     if (ev_start) LPR_HIP(hipEventRecord(ev_start, S));  // both kernels of the previous step done
     const int G = ov_groups(t);
@@ -1731,10 +1798,10 @@ int ov2_launch_step(lpr_tableau* t, int K, int tr, int lp, int flags, hipEvent_t
     const int no_l2 = (flags & 6) ? 1 : 0;
     if (flags & 1)
         hipLaunchKernelGGL((k_ov2_heads<kOvNT, true>), dim3(G * spread), dim3(kOvNT), 0, H, c->b,
-                           t->ld, t->rows, t->cols, c->Rp, K, G, lp, spread, no_l2);
+                           t->ld, t->rows, t->cols, c->Rp, K, G, lp, spread, no_l2, wait_sweeps);
     else
         hipLaunchKernelGGL((k_ov2_heads<kOvNT, false>), dim3(G * spread), dim3(kOvNT), 0, H, c->b,
-                           t->ld, t->rows, t->cols, c->Rp, K, G, lp, spread, no_l2);
+                           t->ld, t->rows, t->cols, c->Rp, K, G, lp, spread, no_l2, wait_sweeps);
     LPR_HIP(hipEventRecord(c->ev_h[cur], H));
     const int nct = (t->ld / 2 + kOvNT - 1) / kOvNT;
     const int nrt = (t->rows + kOvTileRows - 1) / kOvTileRows;
@@ -1745,7 +1812,7 @@ int ov2_launch_step(lpr_tableau* t, int K, int tr, int lp, int flags, hipEvent_t
     const int avoid = (flags & (2 | 4 | 8)) ? 0 : ((flags & 16) ? 1 : 2);
 #define LPR_OV2_SWEEP(TR, DB)                                                                    \
     hipLaunchKernelGGL((k_ov2_sweep<TR, DB>), grid, blk, 0, S, c->b, c->b.fcol, c->b.prow, t->ld, \
-                       t->rows, c->Rp, lp, avoid)
+                       t->rows, c->Rp, lp, avoid, by_event ? 1 : 0)
     switch (ov_tile_code(tr)) {
         case 0x04: LPR_OV2_SWEEP(4, false); break;
         case 0x10: LPR_OV2_SWEEP(16, false); break;
@@ -1755,7 +1822,10 @@ int ov2_launch_step(lpr_tableau* t, int K, int tr, int lp, int flags, hipEvent_t
     }
 #undef LPR_OV2_SWEEP
     if (ev_stop) LPR_HIP(hipEventRecord(ev_stop, S));  // this step's sweep done
-    LPR_HIP(hipEventRecord(c->ev_s[cur], S));
+    c->steps += 1;
+    if (by_event) LPR_HIP(hipEventRecord(c->ev_s[cur], S));
+    else hipLaunchKernelGGL(k_ov_flag, dim3(1), dim3(64), 0, S, c->b.sflag, (unsigned)c->steps);
+    // (hipStreamWriteValue32 instead of the one-lane kernel measured the same: 190.7 vs 188 us)
     c->ev_idx = prev;
     return LPR_OK_OPTIMAL;
 }
