@@ -66,7 +66,7 @@ struct OvBuffers {      // everything the step kernel touches, passed by value
     unsigned long long* xgran;  // [kOvGroups] {launch epoch, XCC id} of every head workgroup
     unsigned long long* hx;     // {launch epoch, 0x100 | XCC id}: the XCD this launch's heads share
     unsigned* tileq;            // [2] next tile of the sweep (work queue), by launch parity
-    unsigned* sflag;            // sweeps completed in this solve call (k_ov_flag behind each sweep)
+    unsigned* sflag;            // sweeps completed in this solve call (stored by the next sweep's start)
     unsigned long long* dbg;    // diagnostic time stamps of the lead head workgroup (or null)
     OvCtl* ctl;         // [2]
     unsigned* bar;      // [2]
@@ -658,8 +658,10 @@ __device__ __forceinline__ void ov_publish_min(Cand c, double* lds_v, int* lds_i
 // wait_sweeps >= 0 (two-stream form): this launch was queued right behind the previous heads,
 // WITHOUT waiting for the sweep that writes the tableau buffer it reads; it does its start-up
 // (placement check, register fills from the staging slots) and then waits until B.sflag -- stored
-// by a one-lane kernel queued behind every sweep -- says that `wait_sweeps` sweeps of this solve
-// call have completed.  The cross-stream event that used to order the two (5-10 us of latency per
+// by the first workgroup of every sweep as it STARTS: sweep k's start means sweeps 0..k-1 of the
+// stream are complete and flushed -- says that `wait_sweeps` sweeps of this solve call have
+// completed.  (The sweep it waits for the start of is the one of its own step, which only waits for
+// the heads of the step before: no cycle.)  The cross-stream event that used to order the two (5-10 us of latency per
 // step, on the critical path whenever the heads end last) is gone.  In this form the heads also own
 // the control-block fields the sweep used to write (applied / cur / sweep parity): the sweep of the
 // same step only reads the control block.
@@ -1406,7 +1408,7 @@ template <int TR, bool DB, bool INPLACE>
 __device__ __forceinline__ void ov_tiles(const OvBuffers& B, const double* __restrict__ fcol,
                                          const double* __restrict__ prow, int ld, int R, int Rp,
                                          int G, int lp, int static_tile, int avoid,
-                                         bool write_ctl = true) {
+                                         bool write_ctl = true, int sweeps_done = -1) {
     static_assert(kOvTileRows % (2 * TR) == 0, "tile rows must be a multiple of two chunks");
     __shared__ int s_tile;
     const OvCtl* ci = B.ctl + lp;
@@ -1414,6 +1416,11 @@ __device__ __forceinline__ void ov_tiles(const OvBuffers& B, const double* __res
     const int cur = ci->cur;
     const bool first_wg = ((int)blockIdx.x == G);
     if (first_wg && threadIdx.x == 0) {  // the next launch's view (fields owned by the sweep)
+        // this launch has started, so every earlier sweep of the stream is complete and its
+        // stores are visible (kernel boundary): tell the heads that wait for exactly that
+        if (sweeps_done >= 0)
+            __hip_atomic_store(B.sflag, (unsigned)sweeps_done, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
         OvCtl* co = B.ctl + (lp ^ 1);
         if (write_ctl) {  // (the heads write these when they run ahead of the event, see there)
             co->applied = ci->applied + K;
@@ -1496,19 +1503,16 @@ __global__ __launch_bounds__(NT) void k_ov2_heads(const OvBuffers B, int ld, int
     ov_heads_rich<NT, STAMP>(B, ld, R, C, Rp, K, G, lp, false, spread, no_l2, wait_sweeps);
 }
 
-// queued behind every sweep of the two-stream form: "n sweeps of this solve call are complete"
-__global__ void k_ov_flag(unsigned* flag, unsigned n) {
-    if (threadIdx.x == 0 && blockIdx.x == 0)
-        __hip_atomic_store(flag, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
+
 
 template <int TR, bool DB>
 __global__ __launch_bounds__(kOvNT) void k_ov2_sweep(const OvBuffers B,
                                                      const double* __restrict__ fcol_ro,
                                                      const double* __restrict__ prow_ro, int ld,
                                                      int R, int Rp, int lp, int avoid,
-                                                     int write_ctl) {
-    ov_tiles<TR, DB, false>(B, fcol_ro, prow_ro, ld, R, Rp, 0, lp, -1, avoid, write_ctl != 0);
+                                                     int write_ctl, int sweeps_done) {
+    ov_tiles<TR, DB, false>(B, fcol_ro, prow_ro, ld, R, Rp, 0, lp, -1, avoid, write_ctl != 0,
+                            sweeps_done);
 }
 
 // The same two halves as separate launches: all K loop heads of a block in ONE persistent launch
@@ -1812,7 +1816,7 @@ int ov2_launch_step(lpr_tableau* t, int K, int tr, int lp, int flags, hipEvent_t
     const int avoid = (flags & (2 | 4 | 8)) ? 0 : ((flags & 16) ? 1 : 2);
 #define LPR_OV2_SWEEP(TR, DB)                                                                    \
     hipLaunchKernelGGL((k_ov2_sweep<TR, DB>), grid, blk, 0, S, c->b, c->b.fcol, c->b.prow, t->ld, \
-                       t->rows, c->Rp, lp, avoid, by_event ? 1 : 0)
+                       t->rows, c->Rp, lp, avoid, by_event ? 1 : 0, by_event ? -1 : c->steps)
     switch (ov_tile_code(tr)) {
         case 0x04: LPR_OV2_SWEEP(4, false); break;
         case 0x10: LPR_OV2_SWEEP(16, false); break;
@@ -1824,8 +1828,6 @@ int ov2_launch_step(lpr_tableau* t, int K, int tr, int lp, int flags, hipEvent_t
     if (ev_stop) LPR_HIP(hipEventRecord(ev_stop, S));  // this step's sweep done
     c->steps += 1;
     if (by_event) LPR_HIP(hipEventRecord(c->ev_s[cur], S));
-    else hipLaunchKernelGGL(k_ov_flag, dim3(1), dim3(64), 0, S, c->b.sflag, (unsigned)c->steps);
-    // (hipStreamWriteValue32 instead of the one-lane kernel measured the same: 190.7 vs 188 us)
     c->ev_idx = prev;
     return LPR_OK_OPTIMAL;
 }
