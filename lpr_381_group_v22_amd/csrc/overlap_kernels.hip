@@ -1790,9 +1790,13 @@ int ov2_launch_step(lpr_tableau* t, int K, int tr, int lp, int flags, hipEvent_t
     lpr_overlap_ctx* c = static_cast<lpr_overlap_ctx*>(t->ov);
     hipStream_t S = t->eng->stream, H = c->hstream;
     const int cur = c->ev_idx, prev = cur ^ 1;
-    // flags 32: the round-1 hand-over (the heads wait for the previous sweep by a cross-stream
-    // event); default: the heads follow their predecessor at once and wait on the device (B.sflag)
-    const bool by_event = (flags & 32) != 0;
+    // default: the heads wait for the previous sweep by a cross-stream event.  flags 32: they
+    // follow their predecessor at once and wait on the device (B.sflag) -- 3 % faster, but it
+    // NEEDS the two kernels of a step to run concurrently: under a tool that serialises kernels
+    // (rocprofv3 --pmc does) the heads would wait for a sweep that cannot start, until the bounded
+    // wait gives up with LPR_DEVICE_ERROR.  A solver must not depend on concurrency for progress,
+    // so it is opt-in.
+    const bool by_event = (flags & 32) == 0;
     const int wait_sweeps = by_event ? -1 : c->steps;
     if (by_event) LPR_HIP(hipStreamWaitEvent(H, c->ev_s[prev], 0));
     LPR_HIP(hipStreamWaitEvent(S, c->ev_h[prev], 0));

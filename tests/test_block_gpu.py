@@ -21,11 +21,11 @@ SEQ, OV, INPLACE, OV2 = 0x4008, 0x5008, 0x6008, 0x3008
 # anywhere on the chip with memory-side hand-offs (the round-1 form), MEMSIDE = confined but
 # memory-side hand-offs, STAMPS = the diagnostic build.  Same bits every way.
 STAMPS, SPREAD, MEMSIDE = 0x10000, 0x20000, 0x40000
-NOAVOID, NOHINT, BYEVENT = 0x80000, 0x100000, 0x200000  # sweep / hand-over variants (ABI header)
+NOAVOID, NOHINT, DEVHAND = 0x80000, 0x100000, 0x200000  # sweep / hand-over variants (ABI header)
 NAMES = {SEQ: "seq", OV: "ov", INPLACE: "inplace", OV2: "ov2",
          SEQ | SPREAD: "seq-spread", OV2 | SPREAD: "ov2-spread", OV2 | MEMSIDE: "ov2-memside",
          SEQ | STAMPS: "seq-stamps", OV2 | STAMPS: "ov2-stamps",
-         OV2 | BYEVENT: "ov2-byevent", OV2 | NOAVOID: "ov2-noavoid", OV2 | NOHINT: "ov2-nohint",
+         OV2 | DEVHAND: "ov2-devhand", OV2 | NOAVOID: "ov2-noavoid", OV2 | NOHINT: "ov2-nohint",
          0x3024: "ov2-2x4", 0x3028: "ov2-2x8", 0x3004: "ov2-4", 0x3010: "ov2-16",
          0x4024: "seq-2x4", 0x4028: "seq-2x8", 0x4010: "seq-16"}
 # (variant, block)
@@ -33,7 +33,7 @@ BLOCKS = [(SEQ, 2), (SEQ, 5), (SEQ, 8), (SEQ, 16), (OV, 2), (OV, 3), (OV, 8), (O
           (OV2, 2), (OV2, 7), (OV2, 16),
           (INPLACE, 2), (INPLACE, 4), (INPLACE, 8),
           (SEQ | SPREAD, 16), (OV2 | SPREAD, 16), (OV2 | MEMSIDE, 9), (SEQ | STAMPS, 16),
-          (OV2 | STAMPS, 13), (OV2 | BYEVENT, 16), (OV2 | NOAVOID, 16), (OV2 | NOHINT, 6),
+          (OV2 | STAMPS, 13), (OV2 | DEVHAND, 16), (OV2 | DEVHAND, 3), (OV2 | NOAVOID, 16), (OV2 | NOHINT, 6),
           (0x3024, 16), (0x3028, 16), (0x3004, 16), (0x3010, 16),
           (0x4024, 16), (0x4028, 11), (0x4010, 16)]
 IDS = [NAMES[v] + str(b) for v, b in BLOCKS]
@@ -322,9 +322,9 @@ def north_star_64(oracle):
     return _north_star_oracle(oracle, 64)
 
 
-@pytest.mark.parametrize("variant", [0, SPREAD, MEMSIDE, BYEVENT, NOAVOID, 0x4008, 0x5008, 0x3024,
+@pytest.mark.parametrize("variant", [0, SPREAD, MEMSIDE, DEVHAND, NOAVOID, 0x4008, 0x5008, 0x3024,
                                      0x3028, 0x3004],
-                         ids=["default", "default-spread", "default-memside", "default-byevent",
+                         ids=["default", "default-spread", "default-memside", "default-devhand",
                               "default-noavoid", "seq", "ov", "ov2-2x4", "ov2-2x8", "ov2-4"])
 def test_north_star_size_64_pivots_vs_oracle(engine, north_star_64, variant):
     """BASELINE's headline size (m=4096, n=8192: 4097 x 12289, 25 loop-head workgroups): four full

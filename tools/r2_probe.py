@@ -71,8 +71,8 @@ def main():
     quick = "--quick" in sys.argv
     m, n = 4096, 8192
     eng = pkg.Engine(0)
-    NOAVOID, NOHINT, BYEVENT = 0x80000, 0x100000, 0x200000
-    heads = (("confined+L2, sweep leaves the XCD", 0), ("same, hand-over by event", BYEVENT),
+    NOAVOID, NOHINT, DEVHAND = 0x80000, 0x100000, 0x200000
+    heads = (("confined+L2, sweep leaves the XCD", 0), ("same, hand-over on the device", DEVHAND),
              ("same, live word only", NOHINT),
              ("confined+L2, sweep everywhere", NOAVOID), ("confined+memside", MEMSIDE),
              ("spread", SPREAD))
