@@ -93,13 +93,22 @@ class Dist:
             raise SystemExit(f"WORLD_SIZE={self.world} does not match --gpus {args.gpus}")
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
-        torch.cuda.set_device(self.local_rank)
+        # Rehearsal of the N > 1 code path on a one-GPU box: every rank uses GPU 0 and the bench's
+        # own collectives go over gloo (RCCL refuses two ranks on one device).  The line it prints
+        # is marked "rehearsal" -- it is a test of the plumbing, never a measurement.
+        self.shared_gpu = os.environ.get("LPR_BENCH_SHARED_GPU", "") == "1" and self.world > 1
+        self.device_index = 0 if self.shared_gpu else self.local_rank
+        self.tensor_device = "cpu" if self.shared_gpu else "cuda"
+        torch.cuda.set_device(self.device_index)
         self.dist = None
         if self.world > 1:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group(backend="nccl",
-                                    device_id=torch.device("cuda", self.local_rank))
+            if self.shared_gpu:
+                dist.init_process_group(backend="gloo")
+            else:
+                dist.init_process_group(backend="nccl",
+                                        device_id=torch.device("cuda", self.local_rank))
             self.dist = dist
 
     def barrier(self, eng=None):
@@ -110,13 +119,13 @@ class Dist:
             eng.sync()
 
     def max(self, v: float) -> float:
-        t = self.torch.tensor([v], dtype=self.torch.float64, device="cuda")
+        t = self.torch.tensor([v], dtype=self.torch.float64, device=self.tensor_device)
         if self.dist is not None:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
     def sum(self, v: float) -> float:
-        t = self.torch.tensor([v], dtype=self.torch.float64, device="cuda")
+        t = self.torch.tensor([v], dtype=self.torch.float64, device=self.tensor_device)
         if self.dist is not None:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return float(t.item())
@@ -142,7 +151,7 @@ def run_primal(args, D: Dist):
     m, n, K, W = args.m, args.n, args.steps, args.warmup
     R, C = m + 1, n + m + 1
     bytes_per_pivot = 2 * 8 * R * C  # every tableau element read once + written once
-    eng = pkg.Engine(D.local_rank)
+    eng = pkg.Engine(D.device_index)
     tab = pkg.Tableau.synthetic(eng, m, n, D.rank)  # one LP replica per rank (seed = rank)
     timed = not args.no_kernel_timing
     # one pivot to learn how many pivots a step of the path chosen for this tableau applies
@@ -284,7 +293,7 @@ def run_primal(args, D: Dist):
 def run_revised(args, D: Dist):
     import lpr_381_group_v22_amd as pkg
     m, n, K, W = args.m, args.n, args.steps, args.warmup
-    eng = pkg.Engine(D.local_rank)
+    eng = pkg.Engine(D.device_index)
     st = pkg.RevisedState.synthetic(eng, m, n, D.rank)
     if W > 0:
         st.solve(max_pivots=W)
@@ -371,7 +380,7 @@ def run_bb(args, D: Dist):
     import lpr_381_group_v22_amd as pkg
     from lpr_381_group_v22_amd import Constraint
     nv, nc, levels = args.bb_vars, args.bb_cons, args.bb_levels
-    eng = pkg.Engine(D.local_rank)
+    eng = pkg.Engine(D.device_index)
     c, A, b = bb_instance(nv, nc, 7)
     cons = [Constraint(A[i].tolist(), "<=", float(b[i])) for i in range(nc)]
     for i in range(nv):  # Program.cs:372-382
@@ -387,7 +396,22 @@ def run_bb(args, D: Dist):
     if D.dist is not None:
         ids = [pkg.Comm.unique_id() if D.rank == 0 else None]
         D.dist.broadcast_object_list(ids, src=0)
-        comm = pkg.Comm.rccl(eng, D.rank, D.world, ids[0])
+        if D.shared_gpu:  # rehearsal: the library's collectives carried by gloo callbacks
+            import torch
+
+            def _armax(vals):
+                t = torch.tensor(vals, dtype=torch.float64)
+                D.dist.all_reduce(t, op=D.dist.ReduceOp.MAX)
+                return t.tolist()
+
+            def _agather(blob):
+                parts = [None] * D.world
+                D.dist.all_gather_object(parts, blob)
+                return parts
+
+            comm = pkg.Comm.custom(D.rank, D.world, _armax, _agather)
+        else:
+            comm = pkg.Comm.rccl(eng, D.rank, D.world, ids[0])
     D.barrier(eng)
     t0 = time.perf_counter()
     res = pkg.solve_level_sync_native(tree, comm, max_levels=levels)
@@ -461,7 +485,7 @@ def run_sens(args, D: Dist):
     m, n, K, W = args.m, args.n, args.steps, args.warmup
     R, C = m + 1, n + m + 1
     bytes_per_pivot = 2 * 8 * R * C
-    eng = pkg.Engine(D.local_rank)
+    eng = pkg.Engine(D.device_index)
     tab = pkg.Tableau.synthetic(eng, m, n, D.rank)
     t0 = time.perf_counter()
     res = tab.solve()
@@ -545,6 +569,9 @@ def main() -> int:
            "sens": run_sens}[args.workload](args, D)
     D.finish()
     if out is not None:
+        if D.shared_gpu:
+            out["rehearsal"] = (f"{D.world} ranks SHARE one GPU, collectives over gloo: a test of "
+                                "the multi-rank plumbing, not a measurement")
         print(json.dumps(out), flush=True)
     return 0
 

@@ -29,6 +29,14 @@
 
 #pragma clang fp contract(off)
 
+// tools/sweep_bench.hip compiles this file with LPR_OV_KERNELS_ONLY and LPR_OV_DIAG bits to take
+// the sweep apart (1: no multiply-subtract chains, 2: no pivot-row loads, 4: half the chains,
+// 8: plain instead of non-temporal loads / stores, 16: static grid with every XCD on a contiguous
+// range of tiles, 32: tiles taken column-major).  The library is built with neither.
+#ifndef LPR_OV_DIAG
+#define LPR_OV_DIAG 0
+#endif
+
 namespace lpr {
 
 constexpr int kOvMax = 16;      // pivots per block, upper bound
@@ -1216,15 +1224,17 @@ typedef double ov_v2d __attribute__((ext_vector_type(2)));
 template <int TR>
 __device__ __forceinline__ void ov_chunk(ov_v2d (&x)[TR], const ov_v2d (&p)[kOvMax],
                                          const double* __restrict__ fci, int Rp) {
+    if (LPR_OV_DIAG & 1) return;
+    constexpr int kSteps = (LPR_OV_DIAG & 4) ? kOvMax / 2 : kOvMax;
     double fn[TR];
 #pragma unroll
     for (int k = 0; k < TR; ++k) fn[k] = fci[k];  // wave-uniform: one scalar load
 #pragma unroll
-    for (int s = 0; s < kOvMax; ++s) {
+    for (int s = 0; s < kSteps; ++s) {
         double f[TR];
 #pragma unroll
         for (int k = 0; k < TR; ++k) f[k] = fn[k];
-        if (s + 1 < kOvMax) {
+        if (s + 1 < kSteps) {
             size_t off = (size_t)(s + 1) * Rp;  // (the pointer itself must stay derived from the
             asm volatile("" : "+s"(off) : "s"(f[0]));  // __restrict__ argument: scalar loads)
 #pragma unroll
@@ -1246,7 +1256,9 @@ __device__ __forceinline__ void ov_chunk(ov_v2d (&x)[TR], const ov_v2d (&p)[kOvM
 template <int TR, bool INPLACE>
 __device__ __forceinline__ void ov_rows_load(ov_v2d (&x)[TR], const ov_v2d* src, int ld2) {
 #pragma unroll
-    for (int k = 0; k < TR; ++k) x[k] = INPLACE ? src[(size_t)k * ld2] : ov_ld_stream(&src[(size_t)k * ld2]);
+    for (int k = 0; k < TR; ++k)
+        x[k] = (INPLACE || (LPR_OV_DIAG & 8)) ? src[(size_t)k * ld2]
+                                              : ov_ld_stream(&src[(size_t)k * ld2]);
 }
 
 template <int TR, bool INPLACE>
@@ -1255,7 +1267,7 @@ __device__ __forceinline__ void ov_rows_store(const ov_v2d (&x)[TR], ov_v2d* dst
 #pragma unroll
     for (int k = 0; k < TR; ++k) {
         if ((skip >> k) & 1u) continue;  // a pivot row of the block: recomputed afterwards
-        if (INPLACE) dst[(size_t)k * ld2] = x[k];
+        if (INPLACE || (LPR_OV_DIAG & 8)) dst[(size_t)k * ld2] = x[k];
         else __builtin_nontemporal_store(x[k], &dst[(size_t)k * ld2]);
     }
 }
@@ -1282,7 +1294,16 @@ __device__ __forceinline__ void ov_one_tile(const OvBuffers& B, const OvCtl* ci,
     const int ld2 = ld >> 1;
     const int nct = (ld2 + kOvNT - 1) / kOvNT;
     const int nrt = (R + kOvTileRows - 1) / kOvTileRows;
+    if (LPR_OV_DIAG & 16) {  // workgroup b sits on XCD b % 8: give each XCD consecutive tiles
+        const int per = (nct * nrt + 7) / 8;
+        tb = (tb % 8) * per + tb / 8;
+    }
     int ct = tb % nct, rt = tb / nct;
+    if (LPR_OV_DIAG & 32) {
+        rt = tb % nrt;
+        ct = tb / nrt;
+        if (ct >= nct) return;
+    }
     if (rt >= nrt) return;
     if (ci->sweep & 1) {
         ct = nct - 1 - ct;
@@ -1297,7 +1318,10 @@ __device__ __forceinline__ void ov_one_tile(const OvBuffers& B, const OvCtl* ci,
     // flight at once (rows >= K of the staging slot are stale but valid memory; they are not used)
     v2d p[kOvMax];
 #pragma unroll
-    for (int s = 0; s < kOvMax; ++s) p[s] = prow2[(size_t)s * ld2 + c2];
+    for (int s = 0; s < kOvMax; ++s) {
+        if (LPR_OV_DIAG & 2) p[s] = v2d{(double)c2, (double)s};
+        else p[s] = prow2[(size_t)s * ld2 + c2];
+    }
     const int ibase = rt * kOvTileRows;
     const int iend = min(R, ibase + kOvTileRows);
 
@@ -1536,6 +1560,7 @@ __global__ __launch_bounds__(kOvNT) void k_ov_sweep(const OvBuffers B,
 
 }  // namespace lpr
 
+#ifndef LPR_OV_KERNELS_ONLY
 // ---------------------------------------------------------------------------------------------
 // host side (the driver loop lives in lpr_engine.hip)
 
@@ -1894,3 +1919,4 @@ void ov_adopt_buffer(lpr_tableau* t, int cur) {
 }
 
 }  // namespace lpr
+#endif  // LPR_OV_KERNELS_ONLY

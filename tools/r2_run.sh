@@ -34,6 +34,12 @@ for step in "$@"; do
       run prof_bb 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_bbkt -o kt -- python3 bench.py --workload bb --cpu-pivots 0
       find gpurun_out/${tag}_bbkt -name "*kernel_stats*" -exec cp {} gpurun_out/${tag}_bb_kernel_stats.csv \;
       find gpurun_out/${tag}_bbkt -name "*kernel_trace*" -delete ;;
+    rehearse-n2)  # the N > 1 code path of bench.py with 2 ranks on this box's one GPU (gloo)
+      export LPR_BENCH_SHARED_GPU=1
+      run rehearse_primal 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 20 --warmup 5
+      run rehearse_bb 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29518 bench.py --gpus 2 --workload bb
+      run rehearse_revised 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29519 bench.py --gpus 2 --workload revised --steps 32 --warmup 4
+      unset LPR_BENCH_SHARED_GPU ;;
     probe) run probe 600 python tools/r2_probe.py ;;
     probe-quick) run probe 300 python tools/r2_probe.py --quick ;;
     bench) run bench 600 python bench.py ; run bench_driver 600 python bench.py --gpus 1 --steps 20 --warmup 5 ;;
