@@ -40,6 +40,12 @@ for step in "$@"; do
       run rehearse_bb 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29518 bench.py --gpus 2 --workload bb
       run rehearse_revised 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29519 bench.py --gpus 2 --workload revised --steps 32 --warmup 4
       unset LPR_BENCH_SHARED_GPU ;;
+    trace-gaps)
+      rm -rf gpurun_out/${tag}_gaps
+      run prof_gaps 600 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/${tag}_gaps -o kt -- python3 bench.py --steps 64 --warmup 8 --cpu-pivots 0
+      python tools/hop_from_trace.py $(find gpurun_out/${tag}_gaps -name "*kernel_trace.csv" | head -n 1) > gpurun_out/${tag}_step_gaps.json
+      cat gpurun_out/${tag}_step_gaps.json
+      rm -rf gpurun_out/${tag}_gaps ;;
     probe) run probe 600 python tools/r2_probe.py ;;
     probe-quick) run probe 300 python tools/r2_probe.py --quick ;;
     bench) run bench 600 python bench.py ; run bench_driver 600 python bench.py --gpus 1 --steps 20 --warmup 5 ;;
