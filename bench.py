@@ -207,7 +207,9 @@ def run_primal(args, D: Dist):
             achieved = bytes_per_pivot / (kern_ms * 1e-3) / 1e9
             roof.update({"achieved": round(achieved, 1),
                          "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                         "frac_vs_measured_copy_6290": round(achieved / 6290.0, 4),
+                         # hipMemcpyDtoD of the same 403 MB on the same part: 155.6 us = 5.18 TB/s
+                         # (profiles/r02_sweep_floor_probe.jsonl): what an out-of-place copy achieves
+                         "frac_vs_measured_copy_5180": round(achieved / 5180.0, 4),
                          "avg_launch_ms": round(kern_ms, 6), "launches": launches,
                          "event_sampling": ("every sweep launch of the timed region that applied "
                                             "a full block" if B > 1 else
