@@ -9,8 +9,8 @@
 //                              with a spin barrier between the two phases of a head.
 //   ov_tiles                   the sweep: 32-row x 256-double2 tiles.
 // and three ways of putting them on the device (lpr_engine.hip picks by tableau size):
-//   k_ov_heads + k_ov_sweep    heads, then the sweep in place (0x40tr; 12 MB .. 300 MB).
-//   k_ov2_heads || k_ov2_sweep two kernels on two streams (0x30tr; above 300 MB): the sweep is out
+//   k_ov_heads + k_ov_sweep    heads, then the sweep in place (0x40tr; 12 MB .. 80 MB).
+//   k_ov2_heads || k_ov2_sweep two kernels on two streams (0x30tr; above 80 MB): the sweep is out
 //                              of place (tableau buffer `cur` -> `cur ^ 1`), so while it runs the
 //                              buffer it reads is still the tableau BEFORE the block, and the heads
 //                              of the next block work from that very buffer, taking every column /

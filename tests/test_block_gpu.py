@@ -342,6 +342,27 @@ def test_north_star_size_64_pivots_vs_oracle(engine, north_star_64, variant):
     tab.destroy()
 
 
+@pytest.mark.parametrize("m,n", [(2048, 4096), (1792, 3584)], ids=["101MB", "77MB"])
+def test_mid_size_default_path_vs_oracle(engine, oracle, m, n):
+    """Either side of the size where the default changes from heads-then-sweep to the two-stream
+    overlap (80 MB): 80 pivots in two legs through the DEFAULT path against the oracle -- status,
+    pivot log, basis, every byte of the tableau."""
+    from lpr_381_group_v22_amd import Tableau
+    T, basis = oracle.gen_dense_tableau(m, n, 3)
+    st, piv, log = oracle.primal_solve(T, basis, 80)
+    tab = Tableau.synthetic(engine, m, n, 3)
+    total = 0
+    for leg in (33, 47):
+        res = tab.solve(max_pivots=leg)
+        total += res.pivots
+        assert res.block == 16
+    assert total == piv and res.status == st
+    assert tab.pivot_log().tolist() == log.tolist()
+    assert tab.basis().tolist() == basis.tolist()
+    assert tab.read().tobytes() == T.tobytes()
+    tab.destroy()
+
+
 def test_north_star_size_ragged_legs_vs_oracle(engine, oracle):
     """The same size in legs that cut blocks (1 + 37 + 32 pivots, the bench's probe / warm-up /
     timed pattern) with kernel timing on: the tableau after 70 pivots equals the oracle's."""
