@@ -28,7 +28,7 @@ struct BBSlot {
     int32_t var;       // branching variable
     int32_t crow;      // index of the appended constraint row
     int32_t trace_n;   // entries written to this slot's pivot trace
-    int32_t pad;
+    int32_t big;       // set by k_bb_round: a rounded entry is >= 1e11 or not finite
     double bound;
     const double* parent;  // parent node's (rounded) tableau, (rows-1) x (cols-1)
 };
@@ -47,6 +47,7 @@ struct lpr_bb {
         double* T = nullptr;
         int rows = 0, cols = 0, depth = 0;
         bool live = false;
+        bool big = true;   // rounding the stored tableau again could change it (unknown: yes)
     };
     std::vector<Node> nodes;          // node id -> buffer
     std::vector<double*> free_bufs;   // recycled device buffers
@@ -80,4 +81,10 @@ struct lpr_bb {
     int best_node = -1;
     bool found = false;
     int64_t total_pivots = 0;
+    // host-side wall time of the level-synchronous driver by part (seconds; LPR_BB_TIMING=1 prints
+    // them to stderr when lpr_bb_solve_level_sync returns)
+    struct Prof {
+        double alloc = 0, slots = 0, info = 0, expand = 0, poll = 0, comm = 0;
+        int mallocs = 0, polls = 0, steps = 0;
+    } prof;
 };

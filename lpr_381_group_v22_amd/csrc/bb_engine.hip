@@ -7,6 +7,9 @@
 // children that are evaluated together.  Node tableaux never leave HBM.  No CPU fallback.
 #include "bb_common.hpp"
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 
 #include <cmath>
@@ -76,12 +79,21 @@ void bb_orphan(lpr_bb* b) {
     b->eng = nullptr;
 }
 
+static double bb_now() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 static int bb_alloc_buf(lpr_bb* b, double** out) {
     if (!b->free_bufs.empty()) {
         *out = b->free_bufs.back();
         b->free_bufs.pop_back();
         return LPR_OK_OPTIMAL;
     }
+    const double t0 = bb_now();
+    struct Acc {
+        lpr_bb* b; double t0;
+        ~Acc() { b->prof.alloc += bb_now() - t0; b->prof.mallocs += 1; }
+    } acc{b, t0};
     // grow the pool by a slab of buffers at a time (hundreds of children per level: one
     // hipMalloc each would cost more than solving them)
     const size_t bytes = b->buf_elems * sizeof(double);
@@ -107,6 +119,10 @@ static int bb_alloc_buf(lpr_bb* b, double** out) {
 
 static int bb_ensure_slots(lpr_bb* b, int need) {
     if (need <= b->slot_cap) return LPR_OK_OPTIMAL;
+    struct Acc {
+        lpr_bb* b; double t0;
+        ~Acc() { b->prof.slots += bb_now() - t0; }
+    } acc{b, bb_now()};
     int cap = b->slot_cap ? b->slot_cap : 2;
     while (cap < need) cap *= 2;
     LPR_HIP(hipStreamSynchronize(b->eng->stream));
@@ -174,7 +190,12 @@ static int bb_node_info(lpr_bb* b, const int32_t* ids, int count, double* z_out,
     }
     LPR_HIP(hipMemcpyAsync(b->d_slots, b->h_slots, (size_t)count * sizeof(BBSlot),
                            hipMemcpyHostToDevice, st));
-    bb_launch_round(b, count, rows_max, 0);  // currentTableaux = RoundAllTableaux(...) :1047
+    // currentTableaux = RoundAllTableaux(...) :1047.  A node stored by bb_expand has been rounded
+    // once already (:1124 / :1187); below 1e11 rounding is idempotent, so the pass is skipped unless
+    // a node of the batch holds a larger (or non-finite) entry, or its history is unknown (the root)
+    bool any_big = false;
+    for (int k = 0; k < count; ++k) any_big = any_big || b->nodes[ids[k]].big;
+    if (any_big) bb_launch_round(b, count, rows_max, 0);
     bb_launch_node_info(b, count);
     LPR_HIP(hipGetLastError());
     LPR_HIP(hipMemcpyAsync(b->h_info, b->info, (size_t)count * (b->nvars + 1) * sizeof(double),
@@ -247,6 +268,8 @@ static int bb_expand(lpr_bb* b, int count, const int32_t* parent_ids, const int3
         LPR_HIP(hipMemcpyAsync(b->h_running, b->d_running, sizeof(int32_t), hipMemcpyDeviceToHost,
                                st));
         LPR_HIP(hipStreamSynchronize(st));
+        b->prof.polls += 1;
+        b->prof.steps += poll;
         if (*b->h_running <= 0) break;
         if (poll < 32) poll *= 2;
         if (++guard > (1 << 16)) {
@@ -283,6 +306,7 @@ static int bb_expand(lpr_bb* b, int count, const int32_t* parent_ids, const int3
         if (s.state == kBBSolved) {
             child_ids_out[k] = bb_new_node(b, s.cur, s.rows, s.cols,
                                            b->nodes[parent_ids[k]].depth + 1);
+            b->nodes[child_ids_out[k]].big = s.big != 0;
             b->free_bufs.push_back(s.nxt);
         } else {
             child_ids_out[k] = -1;
@@ -640,6 +664,8 @@ int lpr_bb_solve_level_sync(lpr_bb* b, lpr_comm* comm, const lpr_bb_sync_opts* o
     LPR_LIVE_BB(b);
     if (!res) return LPR_BAD_ARGUMENT;
     LPR_HIP(hipSetDevice(b->eng->device));
+    const double t_begin = bb_now();
+    b->prof = lpr_bb::Prof();
     lpr_bb_sync_opts o;
     std::memset(&o, 0, sizeof o);
     if (opts) o = *opts;
@@ -656,6 +682,16 @@ int lpr_bb_solve_level_sync(lpr_bb* b, lpr_comm* comm, const lpr_bb_sync_opts* o
     int split_level = 0;
     while ((1 << split_level) < world) ++split_level;
 
+    {
+        // the widest level has at most 2^levels children: size the per-child scratch ONCE (grown
+        // by doubling level after level it cost 4.9 of 37 ms: nine synchronisations and ninety
+        // allocations, two of them pinned)
+        int64_t widest = (int64_t)1 << (max_levels < 10 ? max_levels : 10);
+        if (widest > 2 * max_nodes) widest = 2 * max_nodes;
+        if (widest < 2) widest = 2;
+        int rc = bb_ensure_slots(b, (int)widest);
+        if (rc != LPR_OK_OPTIMAL) return rc;
+    }
     std::vector<Front> frontier{{0, Path()}};
     bool have_best = false;
     double best_z_local = -INFINITY;
@@ -679,7 +715,9 @@ int lpr_bb_solve_level_sync(lpr_bb* b, lpr_comm* comm, const lpr_bb_sync_opts* o
             for (int q = 0; q < cnt; ++q) ids[q] = frontier[q].node;
             zs.assign(cnt, 0.0);
             vals.assign((size_t)cnt * (n > 0 ? n : 1), 0.0);
+            const double t_i = bb_now();
             int rc = bb_node_info(b, ids.data(), cnt, zs.data(), vals.data());
+            b->prof.info += bb_now() - t_i;
             if (rc != LPR_OK_OPTIMAL) return rc;
             for (int q = 0; q < cnt; ++q) {
                 const double* v = vals.data() + (size_t)q * n;
@@ -729,8 +767,10 @@ int lpr_bb_solve_level_sync(lpr_bb* b, lpr_comm* comm, const lpr_bb_sync_opts* o
             child.assign(cnt, -1);
             cst.assign(cnt, 0);
             cpiv.assign(cnt, 0);
+            const double t_e = bb_now();
             int rc = bb_expand(b, cnt, parents.data(), var.data(), bound.data(), kind.data(),
                                child.data(), cst.data(), cpiv.data(), nullptr, nullptr);
+            b->prof.expand += bb_now() - t_e;
             if (rc != LPR_OK_OPTIMAL) return rc;
             for (int q = 0; q < cnt; ++q) {
                 if (count_here) pivots += cpiv[q];
@@ -755,7 +795,9 @@ int lpr_bb_solve_level_sync(lpr_bb* b, lpr_comm* comm, const lpr_bb_sync_opts* o
         //      "someone has hit max_nodes" -- all three decided by every rank from the same sums
         double red[3] = {best_z_local, frontier.empty() ? 0.0 : 1.0,
                          processed > max_nodes ? 1.0 : 0.0};
+        const double t_c = bb_now();
         int rc = comm_all_reduce_max(comm, red, 3);
+        b->prof.comm += bb_now() - t_c;
         if (rc != LPR_OK_OPTIMAL) return rc;
         global_bound = red[0];
         if (red[2] > 0.5) capped = true;
@@ -798,6 +840,14 @@ int lpr_bb_solve_level_sync(lpr_bb* b, lpr_comm* comm, const lpr_bb_sync_opts* o
     }
     if (found && x)
         for (int i = 0; i < n; ++i) x[i] = all[rec_d * (size_t)wr + 6 + i];
+    if (const char* tv = std::getenv("LPR_BB_TIMING"); tv && tv[0] == '1')
+        std::fprintf(stderr,
+                     "lpr_bb timing: total %.3f ms | node_info %.3f | expand %.3f (of which buffer "
+                     "allocation %.3f in %d hipMalloc) | slot scratch %.3f | collectives %.3f | "
+                     "%d polls, %d pivot steps queued\n",
+                     1e3 * (bb_now() - t_begin), 1e3 * b->prof.info, 1e3 * b->prof.expand,
+                     1e3 * b->prof.alloc, b->prof.mallocs, 1e3 * b->prof.slots, 1e3 * b->prof.comm,
+                     b->prof.polls, b->prof.steps);
     res->status = capped ? LPR_BB_NODE_CAP : LPR_OK_OPTIMAL;
     res->found = found ? 1 : 0;
     res->processed = tot_proc;

@@ -60,6 +60,15 @@ __device__ __forceinline__ double dn_round4_twice(double x) {
     return (fabs(r) < 1e11) ? r : dn_round4(r);
 }
 
+// x rounded three times, then DoDualSimplex's -0 -> +0 (what a row of the parent has been through
+// when the child's dual simplex starts: :702, :747, :799, :307-313)
+__device__ __forceinline__ double dn_round4_thrice_clean(double x) {
+    double r = dn_round4(x);
+    if (!(fabs(r) < 1e11)) r = dn_round4(dn_round4(r));
+    if (r == 0.0) r = 0.0;
+    return r;
+}
+
 // ------------------------------------------------------------------ reductions
 struct Cand {
     double v;
@@ -134,8 +143,12 @@ __global__ __launch_bounds__(256) void k_bb_child_init(const BBSlot* __restrict_
         if (i >= Rc) break;
         double v = 0.0;
         if (i < R) {
-            if (j < C - 1) v = dn_round4_twice(P[(size_t)i * ld + j]);
-            else if (j == C) v = dn_round4_twice(P[(size_t)i * ld + (C - 1)]);
+            // rows of the parent are not touched by the eliminations of :756-796, so what
+            // RoundTableau (:799) and the -0 pass of :307-313 would make of them is written here
+            // (k_bb_eliminate reads them WITHOUT rounding again: this is the thrice-rounded value
+            // the C# reads through RoundNumber(updated[..]); it does the same for the new row)
+            if (j < C - 1) v = dn_round4_thrice_clean(P[(size_t)i * ld + j]);
+            else if (j == C) v = dn_round4_thrice_clean(P[(size_t)i * ld + (C - 1)]);
             // j == C - 1: the inserted 0.0; j > C: padding
         } else {
             if (j == s.var) v = 1.0;                        // RoundNumber(1) twice is 1
@@ -232,14 +245,14 @@ __global__ __launch_bounds__(1024) void k_bb_eliminate(const BBSlot* __restrict_
         const double coefficient = dn_round4(T[(size_t)crow * ld + colIndex]);
         int first = INT_MAX;
         for (int row = tid; row < R; row += nt)
-            if (fabs(dn_round4(T[(size_t)row * ld + colIndex]) - 1.0) <= kBBEps) {
+            if (fabs(T[(size_t)row * ld + colIndex] - 1.0) <= kBBEps) {  // (rounded by child_init)
                 first = row;
                 break;
             }
         const int pivotRow = block_min_int(first, lds);  // :763-770
         if (pivotRow != INT_MAX) {
             for (int col = tid; col < Cc; col += nt) {
-                const double pivotVal = dn_round4(T[(size_t)pivotRow * ld + col]);
+                const double pivotVal = T[(size_t)pivotRow * ld + col];  // (rounded by child_init)
                 const double constraintVal = dn_round4(T[(size_t)crow * ld + col]);
                 double newVal;
                 if (reverse) {
@@ -255,24 +268,34 @@ __global__ __launch_bounds__(1024) void k_bb_eliminate(const BBSlot* __restrict_
         q0 = q + 1;
         __syncthreads();  // the next coefficients are read from the row just rewritten
     }
+    // RoundTableau (:799) and the -0 -> +0 of :307-313 for the new row (the other rows: child_init)
+    for (int col = tid; col < Cc; col += nt) {
+        double v = dn_round4(T[(size_t)crow * ld + col]);
+        if (v == 0.0) v = 0.0;
+        T[(size_t)crow * ld + col] = v;
+    }
 }
 
 // grid (ceil(ld/256), rows_max, nslots).  RoundTableau over slot.cur; `clean` adds the
 // `if (x == -0.0) x = 0.0` pass DoDualSimplex applies to the tableau it is handed (:307-313).
-__global__ __launch_bounds__(256) void k_bb_round(const BBSlot* __restrict__ slots, int ld,
-                                                  int clean) {
-    const BBSlot& s = slots[blockIdx.z];
+// slot.big is set when a rounded value is not below 1e11 (or not finite): only then can rounding the
+// tableau AGAIN change it (dn_round4_twice), so the host may skip the next RoundAllTableaux.
+__global__ __launch_bounds__(256) void k_bb_round(BBSlot* __restrict__ slots, int ld, int clean) {
+    BBSlot& s = slots[blockIdx.z];
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= s.cols) return;
     const int i0 = blockIdx.y * kBBRowsPerThread;
+    bool big = false;
 #pragma unroll
     for (int d = 0; d < kBBRowsPerThread; ++d) {
         const int i = i0 + d;
         if (i >= s.rows) break;
         double v = dn_round4(s.cur[(size_t)i * ld + j]);
         if (clean && v == 0.0) v = 0.0;
+        big = big || !(fabs(v) < 1e11);
         s.cur[(size_t)i * ld + j] = v;
     }
+    if (big) atomicOr(&s.big, 1);
 }
 
 // ------------------------------------------------------------------ DoDualSimplex loop head
@@ -620,10 +643,10 @@ void bb_launch_add_constraint(lpr_bb* b, int nslots, int rows_max, int cols_max)
     hipLaunchKernelGGL(k_bb_child_init, egrid, dim3(256), 0, st, b->d_slots, b->ld);
     hipLaunchKernelGGL(k_bb_basic_scan, dim3((cols_max + 63) / 64, nslots), dim3(64), 0, st,
                        b->d_slots, b->ld, b->bflag, b->bkey);
+    // (:799 RoundTableau and the -0 pass of :307-313 are applied by child_init / eliminate as they
+    // write: no separate pass over the children)
     hipLaunchKernelGGL(k_bb_eliminate, dim3(nslots), dim3(1024), (size_t)b->ld * sizeof(int), st,
                        b->d_slots, b->ld, b->bflag, b->bkey, b->blist);
-    hipLaunchKernelGGL(k_bb_round, egrid, dim3(256), 0, st, b->d_slots, b->ld,
-                       1);  // :799 + the clean of :307-313
 }
 
 void bb_launch_pivot_step(lpr_bb* b, int nslots, int rows_max, int cols_max) {
