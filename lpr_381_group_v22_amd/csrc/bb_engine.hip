@@ -29,7 +29,7 @@ int comm_all_gather(lpr_comm* c, const void* send, void* recv, int bytes);
 void bb_launch_copy_in(lpr_bb* b, const double* src, int src_ld, int rows, int cols, double* dst);
 void bb_launch_round(lpr_bb* b, int nslots, int rows_max, int clean);
 void bb_launch_node_info(lpr_bb* b, int count);
-void bb_launch_add_constraint(lpr_bb* b, int nslots, int rows_max, int cols_max);
+void bb_launch_add_constraint(lpr_bb* b, int nslots, int nparents, int rows_max, int cols_max);
 void bb_launch_pivot_step(lpr_bb* b, int nslots, int rows_max, int cols_max);
 void bb_launch_select_only(lpr_bb* b, int nslots, int rows_max, int cols_max);
 
@@ -222,6 +222,9 @@ static int bb_expand(lpr_bb* b, int count, const int32_t* parent_ids, const int3
     if (rc != LPR_OK_OPTIMAL) return rc;
     hipStream_t st = b->eng->stream;
     int rows_max = 0, cols_max = 0;
+    // IdentifyBasicVariables reads the PARENT only: one scan per distinct parent of the batch
+    std::vector<std::pair<int, int>> seen;  // (parent id, scan row); parents come in runs
+    int nparents = 0;
     for (int k = 0; k < count; ++k) {
         const int pid = parent_ids[k];
         if (pid < 0 || pid >= (int)b->nodes.size() || !b->nodes[pid].live) {
@@ -247,6 +250,15 @@ static int bb_expand(lpr_bb* b, int count, const int32_t* parent_ids, const int3
         s.crow = pn.rows;
         s.bound = bound[k];
         s.parent = pn.T;
+        int u = -1;
+        for (size_t q = seen.size(); q-- > 0 && seen.size() - q <= 4;)  // the last few parents
+            if (seen[q].first == pid) { u = seen[q].second; break; }
+        if (u < 0) {
+            u = nparents++;
+            seen.emplace_back(pid, u);
+            b->h_slots[u].rep = k;  // (slot u <= k has been filled already, or is this one)
+        }
+        s.pscan = u;
         rows_max = s.rows > rows_max ? s.rows : rows_max;
         cols_max = s.cols > cols_max ? s.cols : cols_max;
     }
@@ -255,7 +267,7 @@ static int bb_expand(lpr_bb* b, int count, const int32_t* parent_ids, const int3
     *b->h_running = count;
     LPR_HIP(hipMemcpyAsync(b->d_running, b->h_running, sizeof(int32_t), hipMemcpyHostToDevice,
                            st));
-    bb_launch_add_constraint(b, count, rows_max, cols_max);
+    bb_launch_add_constraint(b, count, nparents, rows_max, cols_max);
 
     // DoDualSimplex: pivot steps until every child has left the running states
     int poll = 4;  // pivot steps queued between polls of the running counter (grows to 32)

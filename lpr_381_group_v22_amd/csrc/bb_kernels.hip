@@ -165,18 +165,28 @@ __global__ __launch_bounds__(256) void k_bb_child_init(const BBSlot* __restrict_
 __global__ __launch_bounds__(64) void k_bb_basic_scan(const BBSlot* __restrict__ slots, int ld,
                                                      int32_t* __restrict__ bflag,
                                                      int32_t* __restrict__ bkey) {
-    const BBSlot& s = slots[blockIdx.y];
+    // one scan per distinct PARENT of the batch (its two children share it)
+    const BBSlot& s = slots[slots[blockIdx.y].rep];
     const int R = s.rows - 1, C = s.cols - 1;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= C) return;
     const double* __restrict__ P = s.parent;
     double sum = 0.0;
     int key = R;
-    for (int i = 0; i < R; ++i) {
-        // working = Round(base) :702, then RoundNumber inside Identify :655
-        const double v = dn_round4_twice(P[(size_t)i * ld + k]);
-        sum = sum + v;
-        if (key == R && v == 1.0) key = i;
+    constexpr int U = 8;  // rows in flight per lane (the sum itself stays in row order)
+    for (int i0 = 0; i0 < R; i0 += U) {
+        double x[U];
+#pragma unroll
+        for (int d = 0; d < U; ++d) x[d] = (i0 + d < R) ? P[(size_t)(i0 + d) * ld + k] : 0.0;
+#pragma unroll
+        for (int d = 0; d < U; ++d) {
+            if (i0 + d < R) {
+                // working = Round(base) :702, then RoundNumber inside Identify :655
+                const double v = dn_round4_twice(x[d]);
+                sum = sum + v;
+                if (key == R && v == 1.0) key = i0 + d;
+            }
+        }
     }
     sum = dn_round4(sum);
     bflag[(size_t)blockIdx.y * ld + k] = (fabs(sum - 1.0) <= kBBEps) ? 1 : 0;
@@ -200,8 +210,8 @@ __global__ __launch_bounds__(1024) void k_bb_eliminate(const BBSlot* __restrict_
     const int Rc = s.rows, Cc = s.cols;
     const int R = Rc - 1, C = Cc - 1;
     const int crow = R;
-    const int32_t* __restrict__ flag = bflag + (size_t)blockIdx.x * ld;
-    const int32_t* __restrict__ key = bkey + (size_t)blockIdx.x * ld;
+    const int32_t* __restrict__ flag = bflag + (size_t)s.pscan * ld;
+    const int32_t* __restrict__ key = bkey + (size_t)s.pscan * ld;
     int32_t* __restrict__ list = blist + (size_t)blockIdx.x * ld;
     double* __restrict__ T = s.cur;
     if (tid == 0) s_count = 0;
@@ -595,12 +605,21 @@ __global__ __launch_bounds__(64) void k_bb_node_info(const BBSlot* __restrict__ 
     double* out = info + (size_t)blockIdx.y * (nvars + 1);
     if (i == 0) out[0] = dn_round4(T[C - 1]);
     if (i >= nvars) return;
+    // the scan stops at the first row whose entry rounds to 1: a dependent load per row would cost a
+    // memory round trip each (577 of them), so rows are fetched eight at a time and tested in order
     double val = 0.0;
-    for (int j = 0; j < R; ++j) {
-        const double v = dn_round4(T[(size_t)j * ld + i]);
-        if (fabs(v - 1.0) <= kBBEps) {
-            val = dn_round4(T[(size_t)j * ld + (C - 1)]);
-            break;
+    bool found = false;
+    constexpr int U = 8;
+    for (int j0 = 0; j0 < R && !found; j0 += U) {
+        double v[U];
+#pragma unroll
+        for (int d = 0; d < U; ++d) v[d] = (j0 + d < R) ? T[(size_t)(j0 + d) * ld + i] : 0.0;
+#pragma unroll
+        for (int d = 0; d < U; ++d) {
+            if (!found && j0 + d < R && fabs(dn_round4(v[d]) - 1.0) <= kBBEps) {
+                val = dn_round4(T[(size_t)(j0 + d) * ld + (C - 1)]);
+                found = true;
+            }
         }
     }
     out[1 + i] = val;
@@ -636,12 +655,12 @@ void bb_launch_node_info(lpr_bb* b, int count) {
                        dim3(64), 0, b->eng->stream, b->d_slots, b->ld, b->nvars, b->info);
 }
 
-void bb_launch_add_constraint(lpr_bb* b, int nslots, int rows_max, int cols_max) {
+void bb_launch_add_constraint(lpr_bb* b, int nslots, int nparents, int rows_max, int cols_max) {
     hipStream_t st = b->eng->stream;
     const dim3 egrid((b->ld + 255) / 256, (rows_max + kBBRowsPerThread - 1) / kBBRowsPerThread,
                      nslots);
     hipLaunchKernelGGL(k_bb_child_init, egrid, dim3(256), 0, st, b->d_slots, b->ld);
-    hipLaunchKernelGGL(k_bb_basic_scan, dim3((cols_max + 63) / 64, nslots), dim3(64), 0, st,
+    hipLaunchKernelGGL(k_bb_basic_scan, dim3((cols_max + 63) / 64, nparents), dim3(64), 0, st,
                        b->d_slots, b->ld, b->bflag, b->bkey);
     // (:799 RoundTableau and the -0 pass of :307-313 are applied by child_init / eliminate as they
     // write: no separate pass over the children)
