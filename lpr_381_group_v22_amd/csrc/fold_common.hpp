@@ -19,11 +19,14 @@ constexpr double kFoldEps = 1e-9;
 //      the take is below best - EPS.  So only the left-to-right minima -- about ln(n) of them on
 //      unordered data -- can ever be taken; they are found with one block-wide prefix-min scan
 //      (each thread owns a contiguous chunk, values stay in registers).
-//  (2) the sequential loop is then replayed over those few flagged candidates by the next-take
-//      search: every round finds the FIRST flagged index after the last take with
-//      val < best - EPS (a block-wide min), which is what the C# loop takes next.  Waves without a
-//      flagged candidate skip the scan; the reductions use ballots / readlanes, not the LDS pipe.
+//  (2) the sequential loop is then replayed over those few flagged candidates only.  They are
+//      compacted in index order into LDS (at most kFoldCap of them) and ONE wave walks them, 64 at
+//      a time: a ballot finds the first lane after the last take with val < best - EPS -- what
+//      the C# loop takes next -- with no workgroup barrier per take (a barrier per take was 1.2 us
+//      x ~10 takes).  More candidates than kFoldCap (a long strictly decreasing input): the
+//      next-take search over the whole block, one round per take, as before.
 // lds_i / lds_v: 32 entries each (two banks of one slot per wave, alternating per round).
+constexpr int kFoldCap = 1024;
 __device__ __forceinline__ double readlane_f64(double x, int lane) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
@@ -75,6 +78,60 @@ __device__ __forceinline__ int eps_fold(int lo, int hi, double best, F val, int*
             if (((flags >> k) & 1u) && !(v[k] < exc)) flags &= ~(1u << k);
     }
     int cur = -1;
+    if (cached) {
+        __shared__ double cand_v[kFoldCap];
+        __shared__ int cand_i[kFoldCap];
+        __shared__ int s_res[2];
+        // ordered compaction: exclusive prefix sum of the per-thread candidate counts
+        const int cnt = __popc(flags);
+        int inc = cnt;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            const int o = __shfl_up(inc, off, kWave);
+            if (lane >= off) inc += o;
+        }
+        if (lane == kWave - 1) lds_i[wave] = inc;
+        __syncthreads();
+        const int wt = (lane < nw) ? lds_i[lane] : 0;
+        int before = 0, total = 0;
+        for (int w = 0; w < nw; ++w) {
+            const int x = __builtin_amdgcn_readlane(wt, w);
+            if (w < wave) before += x;
+            total += x;
+        }
+        __syncthreads();  // lds_i is reused by the fallback below
+        if (total <= kFoldCap) {
+            int pos = before + inc - cnt;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                if ((flags >> k) & 1u) {
+                    cand_v[pos] = v[k];
+                    cand_i[pos] = base + k;
+                    ++pos;
+                }
+            }
+            __syncthreads();
+            if (wave == 0) {
+                for (int b0 = 0; b0 < total; b0 += kWave) {
+                    const int k = b0 + lane;
+                    const double x = (k < total) ? cand_v[k] : NAN;
+                    const int xi = (k < total) ? cand_i[k] : 0;
+                    unsigned long long alive = ~0ull;
+                    for (;;) {
+                        const unsigned long long hit = __ballot(x < best - kFoldEps) & alive;
+                        if (hit == 0ull) break;
+                        const int fl = __builtin_amdgcn_readfirstlane(__builtin_ctzll(hit));
+                        best = readlane_f64(x, fl);
+                        cur = __builtin_amdgcn_readlane(xi, fl);
+                        alive = (fl == kWave - 1) ? 0ull : (~0ull << (fl + 1));
+                    }
+                }
+                if (lane == 0) s_res[0] = cur;
+            }
+            __syncthreads();
+            return s_res[0];
+        }
+    }
     for (int round = 0;; ++round) {
         int first = INT_MAX;
         double fv = 0.0;

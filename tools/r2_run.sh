@@ -46,6 +46,11 @@ for step in "$@"; do
       python tools/hop_from_trace.py $(find gpurun_out/${tag}_gaps -name "*kernel_trace.csv" | head -n 1) > gpurun_out/${tag}_step_gaps.json
       cat gpurun_out/${tag}_step_gaps.json
       rm -rf gpurun_out/${tag}_gaps ;;
+    profile-revised)
+      rm -rf gpurun_out/${tag}_revkt
+      run prof_rev 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_revkt -o kt -- python3 bench.py --workload revised --steps 200 --warmup 16 --cpu-pivots 0
+      find gpurun_out/${tag}_revkt -name "*kernel_stats*" -exec cp {} gpurun_out/${tag}_revised_kernel_stats.csv \;
+      find gpurun_out/${tag}_revkt -name "*kernel_trace*" -delete ;;
     probe) run probe 600 python tools/r2_probe.py ;;
     probe-quick) run probe 300 python tools/r2_probe.py --quick ;;
     bench) run bench 600 python bench.py ; run bench_driver 600 python bench.py --gpus 1 --steps 20 --warmup 5 ;;
