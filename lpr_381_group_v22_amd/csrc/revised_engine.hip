@@ -211,7 +211,11 @@ int lpr_revised_solve(lpr_revised* s, const lpr_solve_opts* opts, lpr_revised_re
     LPR_HIP(hipSetDevice(s->eng->device));
     const int64_t start = s->total_iter;
     const int64_t max_iter = o.max_pivots > 0 ? start + o.max_pivots : 0;
+    // iterations queued between two polls of the status word: a poll idles the device for a
+    // round trip (~40 us, a fifth of an iteration at m = 4096), iterations queued behind the end
+    // of a solve return at once (~15 us each): start at 8, double up to 64
     int batch = o.batch > 0 ? o.batch : 8;
+    const int batch_max = o.batch > 0 ? o.batch : 64;
 
     RevState* hs = s->h_state;
     hs->status = kRunning;
@@ -239,6 +243,11 @@ int lpr_revised_solve(lpr_revised* s, const lpr_solve_opts* opts, lpr_revised_re
         const int64_t done = hs->iter - iter;
         iter = hs->iter;
         status = hs->status;
+        if (batch < batch_max) batch = batch * 2 < batch_max ? batch * 2 : batch_max;
+        if (max_iter > 0 && iter + batch > max_iter) {
+            batch = (int)(max_iter - iter);  // no point in queueing past the caller's limit
+            if (batch < 1) batch = 1;
+        }
         if (status == kRunning && done == 0) {
             set_error("revised simplex loop made no progress (device status still running)");
             return LPR_DEVICE_ERROR;

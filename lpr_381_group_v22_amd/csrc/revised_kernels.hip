@@ -37,7 +37,8 @@ constexpr double kEps = 1e-9;  // RevisedPrimalSimplexSolver.cs:12
 // a slack (then u is a column of B^-1, written by k_rev_gather).
 constexpr int kGRP = 16;   // operands fetched from LDS one group ahead of the add chain
 constexpr int kRB = 16;    // rows per workgroup
-constexpr int kKC = 128;   // columns per chunk
+constexpr int kKC = 256;   // columns per chunk (a chunk costs max(walk, one memory round trip): 128 was
+                           // shorter than the round trip)
 
 // Two products in ONE pass over M: lanes 0..15 walk the rows against v (x_B = B^-1 b), lanes
 // 16..31 of the same wave walk the same rows against v2 (u = B^-1 a_e) -- the second walk rides in
@@ -50,85 +51,85 @@ __global__ __launch_bounds__(256) void k_rev_rowsum(const double* __restrict__ M
                                                     const double* __restrict__ v2,
                                                     double* __restrict__ out2,
                                                     const RevState* __restrict__ st, int n) {
-    // +2 doubles per row: rows stay 16-byte aligned and the 16 consumer lanes hit disjoint banks
-    // (kGRP more so that the one-group-ahead prefetch of the last group stays inside the array)
-    __shared__ __attribute__((aligned(16))) double sM[2][kRB][kKC + kGRP + 2];
-    __shared__ __attribute__((aligned(16))) double sv[2][2][kKC + kGRP];
+    // The tiles in LDS hold the PRODUCTS M[i, j] * v[j] (and M[i, j] * v2[j]), each rounded as the
+    // C# rounds it before adding it (:406): the lanes that stage a chunk multiply as they store, the
+    // walking lanes run only the chain of adds (see k_rev_colsum).  +2 doubles per row: rows stay
+    // 16-byte aligned and the 16 consumer lanes hit disjoint banks (kGRP more so that the
+    // one-group-ahead prefetch of the last group stays inside the array).
+    extern __shared__ __attribute__((aligned(16))) double rev_dyn_lds[];
+    typedef double Tile[kRB][kKC + kGRP + 2];
+    Tile* sP = reinterpret_cast<Tile*>(rev_dyn_lds);  // [2 products][2 buffers]: sP[p * 2 + buf]
     if (st->status != kRunning) return;
     const bool two = v2 != nullptr && st->entering >= 0 && st->entering < n;
     const int tid = threadIdx.x;
     const int row0 = blockIdx.x * kRB;
     const int nchunk = (m + kKC - 1) / kKC;
-    // staging map: kRB * kKC / 2 = 1024 double2 per chunk, 4 per lane; row = idx / 64
-    double2 rm[4];
-    double rv = 0.0;
+    // staging map: kRB * kKC / 2 double2 per chunk, NQ per lane; a lane's double2 sit in the same
+    // two columns of NQ rows, so it needs ONE double2 of v (and of v2)
+    constexpr int HK = kKC / 2;           // double2 per row of the chunk
+    constexpr int NQ = kRB * HK / 256;    // per lane
+    constexpr int RS = 256 / HK;          // rows covered by one pass of the 256 lanes
+    double2 rm[NQ];
+    double2 rv = make_double2(0.0, 0.0), rv2 = make_double2(0.0, 0.0);
     auto load_chunk = [&](int k0) {
+        const int gk = k0 + (tid % HK) * 2;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int idx = tid + q * 256;
-            const int r = idx >> 6, k = (idx & 63) * 2;
-            const int gi = row0 + r, gk = k0 + k;
+        for (int q = 0; q < NQ; ++q) {
+            const int gi = row0 + tid / HK + q * RS;
             rm[q] = (gi < m && gk < ld)
                         ? *reinterpret_cast<const double2*>(M + (size_t)gi * ld + gk)
                         : make_double2(0.0, 0.0);
         }
-        if (tid < kKC) rv = (k0 + tid < m) ? v[k0 + tid] : 0.0;
-        else if (two && tid < 2 * kKC) rv = (k0 + tid - kKC < m) ? v2[k0 + tid - kKC] : 0.0;
+        rv.x = (gk < m) ? v[gk] : 0.0;
+        rv.y = (gk + 1 < m) ? v[gk + 1] : 0.0;
+        if (two) {
+            rv2.x = (gk < m) ? v2[gk] : 0.0;
+            rv2.y = (gk + 1 < m) ? v2[gk + 1] : 0.0;
+        }
     };
     auto store_chunk = [&](int buf) {
+        const int k = (tid % HK) * 2;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int idx = tid + q * 256;
-            const int r = idx >> 6, k = (idx & 63) * 2;
-            sM[buf][r][k] = rm[q].x;
-            sM[buf][r][k + 1] = rm[q].y;
+        for (int q = 0; q < NQ; ++q) {
+            const int r = tid / HK + q * RS;
+            sP[buf][r][k] = rm[q].x * rv.x;  // product rounded ...
+            sP[buf][r][k + 1] = rm[q].y * rv.y;
+            if (two) {
+                sP[2 + buf][r][k] = rm[q].x * rv2.x;
+                sP[2 + buf][r][k + 1] = rm[q].y * rv2.y;
+            }
         }
-        if (tid < kKC) sv[buf][0][tid] = rv;
-        else if (two && tid < 2 * kKC) sv[buf][1][tid - kKC] = rv;
     };
     load_chunk(0);
     store_chunk(0);
     __syncthreads();
     double s = 0.0;
+    const bool walker = tid < kRB || (two && tid < 2 * kRB);
     for (int c = 0; c < nchunk; ++c) {
         const int buf = c & 1;
         if (c + 1 < nchunk) load_chunk((c + 1) * kKC);  // in flight under the serial walk below
-        if (tid < kRB || (two && tid < 2 * kRB)) {
-            // the serial walk: the products are independent, only the adds form the chain
+        if (walker) {
+            // columns past m hold products with zero-filled operands; the walk stops at kmax
             const int kmax = min(kKC, m - c * kKC);
-            const double* __restrict__ row = sM[buf][tid & (kRB - 1)];
-            const double* __restrict__ vv = sv[buf][tid / kRB];
+            const double* __restrict__ row = sP[(tid / kRB) * 2 + buf][tid & (kRB - 1)];
             if (kmax == kKC) {
-                double a[kGRP], b[kGRP];
+                double a[kGRP];
 #pragma unroll
-                for (int u = 0; u < kGRP; ++u) {
-                    a[u] = row[u];
-                    b[u] = vv[u];
-                }
+                for (int u = 0; u < kGRP; ++u) a[u] = row[u];
 #pragma unroll
                 for (int k0 = 0; k0 < kKC; k0 += kGRP) {
-                    double na[kGRP], nb[kGRP];
+                    double na[kGRP];
 #pragma unroll
-                    for (int u = 0; u < kGRP; ++u) {  // next group: in flight under the adds below
-                        na[u] = row[k0 + kGRP + u];
-                        nb[u] = vv[k0 + kGRP + u];
-                    }
+                    for (int u = 0; u < kGRP; ++u) na[u] = row[k0 + kGRP + u];
+                    __builtin_amdgcn_sched_barrier(0);  // next group in flight under the adds
 #pragma unroll
-                    for (int u = 0; u < kGRP; ++u) {
-                        const double p = a[u] * b[u];  // product rounded ...
-                        s = s + p;                     // ... then added (:406)
-                    }
+                    for (int u = 0; u < kGRP; ++u) s = s + a[u];  // ... then added (:406)
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int u = 0; u < kGRP; ++u) {
-                        a[u] = na[u];
-                        b[u] = nb[u];
-                    }
+                    for (int u = 0; u < kGRP; ++u) a[u] = na[u];
                 }
             } else {
-                for (int k = 0; k < kmax; ++k) {
-                    const double p = row[k] * vv[k];
-                    s = s + p;
-                }
+                for (int k = 0; k < kmax; ++k) s = s + row[k];
             }
         }
         if (c + 1 < nchunk) store_chunk(buf ^ 1);
@@ -146,90 +147,104 @@ __global__ __launch_bounds__(256) void k_rev_rowsum(const double* __restrict__ M
 // Same producer/consumer shape as k_rev_rowsum, transposed: a workgroup owns CB = 16 columns (one
 // 128-byte line per row), all 256 lanes stream RC-row chunks into LDS, 16 lanes (one per column)
 // walk the chunk in row order.  cols/16 workgroups (512 for A at n = 8192).
-constexpr int kCB = 16;    // columns per workgroup
+constexpr int kCB = 16;    // columns per workgroup on B^-1
+constexpr int kCBA = 32;   // columns per workgroup on A
+constexpr int kRCB = 512;  // rows per chunk on B^-1: a chunk costs max(walk, one memory round trip), and the
+                           // add-only walk of 128 rows (0.45 us) is shorter than the round trip (~1.2 us)
 constexpr int kRC = 128;   // rows per chunk
 
+// CB columns per workgroup (16 per walking wave, CB / 16 waves walk side by side on their own SIMDs).
+// On A (268 MB, from HBM) CB = 32: with one 128-byte line per row and workgroup every DRAM page that
+// is opened serves 128 bytes, and the kernel ran at 3.3 TB/s with or without the walk (measured:
+// deeper prefetch, 256-row chunks, padded strides, the walk removed -- all 79-89 us); 256 bytes per
+// row halve the activations per byte.  On B^-1 (134 MB, Infinity-Cache resident) CB = 16 keeps twice
+// the workgroups and the chain is the bound either way.
+template <int RC, int CB>
 __global__ __launch_bounds__(256) void k_rev_colsum(const double* __restrict__ M, int ld, int rows,
                                                     int cols, const double* __restrict__ v,
                                                     const double* __restrict__ c,
                                                     double* __restrict__ out, int mode,
                                                     const RevState* __restrict__ st) {
-    __shared__ __attribute__((aligned(16))) double sM[2][kRC + kGRP][kCB];
-    __shared__ __attribute__((aligned(16))) double sv[2][kRC + kGRP];
+    // The tile in LDS holds the PRODUCTS v[i] * M[i, j] (each rounded, as the C# rounds it before it
+    // adds it, :420): the 240 lanes that stage a chunk multiply as they store, so the walking lanes
+    // run nothing but the chain of adds -- one LDS operand and one dependent v_add_f64 per step
+    // (with the multiply in the walk a step cost ~25 cycles: 47 us for 4096 rows).
+    extern __shared__ __attribute__((aligned(16))) double rev_dyn_lds[];
+    typedef double Tile[RC + kGRP][CB];
+    Tile* sP = reinterpret_cast<Tile*>(rev_dyn_lds);  // [2]
     if (st->status != kRunning) return;
     const int tid = threadIdx.x;
-    const int j0 = blockIdx.x * kCB;
-    const int nchunk = (rows + kRC - 1) / kRC;
-    // staging map: kRC * kCB / 2 = 1024 double2 per chunk, 4 per lane; row = idx / 8
-    double2 rm[4];
-    double rv = 0.0;
+    const int j0 = blockIdx.x * CB;
+    const int nchunk = (rows + RC - 1) / RC;
+    // staging map: RC * CB / 2 double2 per chunk, NQ per lane; CB / 2 double2 per row
+    constexpr int NQ = RC * CB / 2 / 256;
+    constexpr int H = CB / 2;
+    double2 rm[NQ];
+    double rv[NQ];
     auto load_chunk = [&](int i0) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             const int idx = tid + q * 256;
-            const int r = idx >> 3, cc = (idx & 7) * 2;
+            const int r = idx / H, cc = (idx % H) * 2;
             const int gi = i0 + r;
-            rm[q] = (gi < rows)
+            rm[q] = (gi < rows && j0 + cc < ld)
                         ? *reinterpret_cast<const double2*>(M + (size_t)gi * ld + j0 + cc)
                         : make_double2(0.0, 0.0);
+            rv[q] = (gi < rows) ? v[gi] : 0.0;
         }
-        if (tid < kRC) rv = (i0 + tid < rows) ? v[i0 + tid] : 0.0;
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             const int idx = tid + q * 256;
-            const int r = idx >> 3, cc = (idx & 7) * 2;
-            *reinterpret_cast<double2*>(&sM[buf][r][cc]) = rm[q];
+            const int r = idx / H, cc = (idx % H) * 2;
+            double2 p;
+            p.x = rv[q] * rm[q].x;  // v[i] * M[i, j] rounded ...
+            p.y = rv[q] * rm[q].y;
+            *reinterpret_cast<double2*>(&sP[buf][r][cc]) = p;
         }
-        if (tid < kRC) sv[buf][tid] = rv;
     };
     load_chunk(0);
     store_chunk(0);
     __syncthreads();
     double s = 0.0;
+    const int wl = tid & 63;
+    const bool walker = (tid >> 6) < CB / 16 && wl < 16;
+    const int wc = (tid >> 6) * 16 + wl;  // this walker's column of the strip
     for (int ch = 0; ch < nchunk; ++ch) {
         const int buf = ch & 1;
-        if (ch + 1 < nchunk) load_chunk((ch + 1) * kRC);
-        if (tid < kCB) {
-            const int imax = min(kRC, rows - ch * kRC);
-            if (imax == kRC) {
-                double a[kGRP], b[kGRP];
+        if (ch + 1 < nchunk) load_chunk((ch + 1) * RC);
+        if (walker) {
+            // rows past the end of a ragged last chunk hold +0.0 * M = products of zero-filled
+            // operands: the walk stops at imax
+            const int imax = min(RC, rows - ch * RC);
+            if (imax == RC) {
+                double a[kGRP];
 #pragma unroll
-                for (int u = 0; u < kGRP; ++u) {
-                    a[u] = sM[buf][u][tid];
-                    b[u] = sv[buf][u];
-                }
+                for (int u = 0; u < kGRP; ++u) a[u] = sP[buf][u][wc];
 #pragma unroll
-                for (int i0 = 0; i0 < kRC; i0 += kGRP) {
-                    double na[kGRP], nb[kGRP];
+                for (int i0 = 0; i0 < RC; i0 += kGRP) {
+                    double na[kGRP];
 #pragma unroll
-                    for (int u = 0; u < kGRP; ++u) {
-                        na[u] = sM[buf][i0 + kGRP + u][tid];
-                        nb[u] = sv[buf][i0 + kGRP + u];
-                    }
+                    for (int u = 0; u < kGRP; ++u) na[u] = sP[buf][i0 + kGRP + u][wc];
+                    // the next group's LDS reads are issued BEFORE this group's adds (left alone
+                    // the scheduler sinks them to their first use: an LDS round trip per group,
+                    // 20 cycles per step instead of the 10 a dependent add takes)
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int u = 0; u < kGRP; ++u) {
-                        const double p = b[u] * a[u];  // v[i] * M[i, j] rounded ...
-                        s = s + p;                     // ... then added (:420)
-                    }
+                    for (int u = 0; u < kGRP; ++u) s = s + a[u];  // ... then added (:420)
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int u = 0; u < kGRP; ++u) {
-                        a[u] = na[u];
-                        b[u] = nb[u];
-                    }
+                    for (int u = 0; u < kGRP; ++u) a[u] = na[u];
                 }
             } else {
-                for (int i = 0; i < imax; ++i) {
-                    const double p = sv[buf][i] * sM[buf][i][tid];
-                    s = s + p;
-                }
+                for (int i = 0; i < imax; ++i) s = s + sP[buf][i][wc];
             }
         }
         if (ch + 1 < nchunk) store_chunk(buf ^ 1);
         __syncthreads();
     }
-    if (tid < kCB && j0 + tid < cols) out[j0 + tid] = mode ? (c[j0 + tid] - s) : s;
+    if (walker && j0 + wc < cols) out[j0 + wc] = mode ? (c[j0 + wc] - s) : s;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -818,19 +833,44 @@ __global__ __launch_bounds__(256, 2) void k_rev_gemm(const double* __restrict__ 
 // ------------------------------------------------------------------------------------------
 // launchers
 
+// dynamic LDS of k_rev_rowsum: two product tiles x two buffers
+static size_t rev_rowsum_lds() {
+    constexpr size_t bytes = (size_t)4 * kRB * (kKC + kGRP + 2) * sizeof(double);
+    static bool asked = false;
+    if (!asked) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rev_rowsum),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        asked = true;
+    }
+    return bytes;
+}
+
+// dynamic LDS of k_rev_colsum<kRC, CB> (CB = 32: above the 64 KB a kernel gets without asking)
+template <int RC, int CB>
+static size_t rev_colsum_lds() {
+    constexpr size_t bytes = (size_t)(2 * (RC + kGRP) * CB) * sizeof(double);
+    static bool asked = false;
+    if (!asked) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rev_colsum<RC, CB>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        asked = true;
+    }
+    return bytes;
+}
+
 // x_B = B^-1 b, y = c_B B^-1, rc_j = c_j - y.A_j: the head of an iteration (:89-102) and, with the
 // same operands after the pivot, the post-pivot quantities of the snapshot (:217-227).
 void rev_launch_prices(lpr_revised* s) {
     hipStream_t st = s->eng->stream;
     const int m = s->m, n = s->n;
     // x_B = B^-1 b (:89)
-    hipLaunchKernelGGL(k_rev_rowsum, dim3((m + kRB - 1) / kRB), dim3(256), 0, st, s->Binv, s->ldb,
+    hipLaunchKernelGGL(k_rev_rowsum, dim3((m + kRB - 1) / kRB), dim3(256), rev_rowsum_lds(), st, s->Binv, s->ldb,
                        m, s->b, s->xB, (const double*)nullptr, (double*)nullptr, s->state, n);
     // y = c_B B^-1 (:93)
-    hipLaunchKernelGGL(k_rev_colsum, dim3((m + kCB - 1) / kCB), dim3(256), 0, st, s->Binv, s->ldb,
+    hipLaunchKernelGGL((k_rev_colsum<kRCB, kCB>), dim3((m + kCB - 1) / kCB), dim3(256), (rev_colsum_lds<kRCB, kCB>()), st, s->Binv, s->ldb,
                        m, m, s->cB, (const double*)nullptr, s->y, 0, s->state);
     // rc_j = c_j - y.A_j (:96-98)
-    hipLaunchKernelGGL(k_rev_colsum, dim3((n + kCB - 1) / kCB), dim3(256), 0, st, s->A, s->lda, m,
+    hipLaunchKernelGGL((k_rev_colsum<kRC, kCBA>), dim3((n + kCBA - 1) / kCBA), dim3(256), (rev_colsum_lds<kRC, kCBA>()), st, s->A, s->lda, m,
                        n, s->y, s->c, s->rcx, 1, s->state);
 }
 
@@ -850,10 +890,10 @@ void rev_launch_iteration(lpr_revised* s, bool snapshot) {
     hipStream_t st = s->eng->stream;
     const int m = s->m, n = s->n;
     // y = c_B B^-1 (:93)
-    hipLaunchKernelGGL(k_rev_colsum, dim3((m + kCB - 1) / kCB), dim3(256), 0, st, s->Binv, s->ldb,
+    hipLaunchKernelGGL((k_rev_colsum<kRCB, kCB>), dim3((m + kCB - 1) / kCB), dim3(256), (rev_colsum_lds<kRCB, kCB>()), st, s->Binv, s->ldb,
                        m, m, s->cB, (const double*)nullptr, s->y, 0, s->state);
     // rc_j = c_j - y.A_j (:96-98)
-    hipLaunchKernelGGL(k_rev_colsum, dim3((n + kCB - 1) / kCB), dim3(256), 0, st, s->A, s->lda, m,
+    hipLaunchKernelGGL((k_rev_colsum<kRC, kCBA>), dim3((n + kCBA - 1) / kCBA), dim3(256), (rev_colsum_lds<kRC, kCBA>()), st, s->A, s->lda, m,
                        n, s->y, s->c, s->rcx, 1, s->state);
     hipLaunchKernelGGL(k_rev_enter, dim3(1), dim3(1024), 0, st, s->rcx, s->y, s->is_basic, n, m,
                        s->state);
@@ -861,7 +901,7 @@ void rev_launch_iteration(lpr_revised* s, bool snapshot) {
                        s->Binv, s->ldb, n, m, s->acol, s->u, s->state);
     // x_B = B^-1 b (:89) and u = B^-1 a_e (:150; unless the entering variable is a slack) in one
     // pass over B^-1
-    hipLaunchKernelGGL(k_rev_rowsum, dim3((m + kRB - 1) / kRB), dim3(256), 0, st, s->Binv, s->ldb,
+    hipLaunchKernelGGL(k_rev_rowsum, dim3((m + kRB - 1) / kRB), dim3(256), rev_rowsum_lds(), st, s->Binv, s->ldb,
                        m, s->b, s->xB, s->acol, s->u, s->state, n);
     if (snapshot)
         hipLaunchKernelGGL(k_rev_snap_pre, dim3((m + 255) / 256), dim3(256), 0, st, s->u, s->xB,
