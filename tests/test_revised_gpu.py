@@ -89,6 +89,52 @@ def test_synthetic_lp_full_solve(engine, oracle, m, n, seed):
     st.destroy()
 
 
+def _explicit(engine, oracle, c, A, b, max_iter):
+    from lpr_381_group_v22_amd import RevisedState
+    ref = oracle.revised_solve(c, A, b, False, max_iter=max_iter)
+    st = RevisedState.create(engine, c, A, b, False)
+    res = st.solve(max_pivots=max_iter)
+    assert res.status == ref["status"] and res.iterations == ref["iterations"]
+    assert st.log().tolist() == ref["log"].tolist()
+    assert st.basis().tolist() == ref["basis"].tolist()
+    assert st.binv().tobytes() == ref["Binv"].tobytes()
+    assert st.xb().tobytes() == ref["xB"].tobytes()
+    st.destroy()
+    return ref
+
+
+def test_entering_fold_with_thousands_of_prefix_records(engine, oracle):
+    """Reduced costs that GROW with the index: every one of the n = 3000 candidates is a strict
+    prefix record of the fold (more than the 1024 the one-wave replay keeps in LDS), so the
+    block-wide next-take search runs; and the mirror image (costs that shrink: one record)."""
+    rng = np.random.RandomState(5)
+    m, n = 24, 3000
+    A = rng.uniform(0.5, 2.0, size=(m, n))
+    b = rng.uniform(50.0, 100.0, size=m)
+    grow = 1.0 + 1e-3 * np.arange(n)
+    ref = _explicit(engine, oracle, grow, A, b, 40)
+    assert ref["log"][0][1] == n - 1  # the last (largest) reduced cost enters first
+    _explicit(engine, oracle, grow[::-1].copy(), A, b, 40)
+    # steps of 1e-12: a candidate is "better by more than EPS" only every ~1000 indices
+    flat_c = 1.0 + 1e-12 * np.arange(n)
+    ref = _explicit(engine, oracle, flat_c, A, b, 40)
+    assert ref["log"][0][1] == 2002
+
+
+def test_ratio_fold_beyond_the_lds_replay(engine, oracle):
+    """m = 4300 rows (> 4096: the ratio test falls back to the block-wide next-take search) with
+    many ties inside the EPS band (equal right-hand sides and repeated rows), few columns."""
+    rng = np.random.RandomState(6)
+    m, n = 4300, 24
+    base = rng.uniform(0.5, 2.0, size=(43, n))
+    A = np.repeat(base, 100, axis=0)[:m].copy()       # every row a hundred times: tied ratios
+    A += rng.uniform(0.0, 2e-10, size=A.shape)         # ... inside the EPS band, not equal
+    b = np.full(m, 10.0)
+    c = rng.uniform(1.0, 2.0, size=n)
+    ref = _explicit(engine, oracle, c, A, b, 6)
+    assert ref["iterations"] >= 3
+
+
 def test_resume_after_limit(engine, oracle):
     from lpr_381_group_v22_amd import RevisedState
     m, n, seed = 40, 80, 3
