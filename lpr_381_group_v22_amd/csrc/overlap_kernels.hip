@@ -32,7 +32,8 @@
 // tools/sweep_bench.hip compiles this file with LPR_OV_KERNELS_ONLY and LPR_OV_DIAG bits to take
 // the sweep apart (1: no multiply-subtract chains, 2: no pivot-row loads, 4: half the chains,
 // 8: plain instead of non-temporal loads / stores, 16: static grid with every XCD on a contiguous
-// range of tiles, 32: tiles taken column-major).  The library is built with neither.
+// range of tiles, 32: tiles taken column-major, 64 / 128: write-through stores of system / agent
+// scope).  The library is built with neither.
 #ifndef LPR_OV_DIAG
 #define LPR_OV_DIAG 0
 #endif
@@ -1268,6 +1269,14 @@ __device__ __forceinline__ void ov_rows_store(const ov_v2d (&x)[TR], ov_v2d* dst
     for (int k = 0; k < TR; ++k) {
         if ((skip >> k) & 1u) continue;  // a pivot row of the block: recomputed afterwards
         if (INPLACE || (LPR_OV_DIAG & 8)) dst[(size_t)k * ld2] = x[k];
+        else if (LPR_OV_DIAG & 64)
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(&dst[(size_t)k * ld2]),
+                         "v"(x[k])
+                         : "memory");
+        else if (LPR_OV_DIAG & 128)
+            asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(&dst[(size_t)k * ld2]),
+                         "v"(x[k])
+                         : "memory");
         else __builtin_nontemporal_store(x[k], &dst[(size_t)k * ld2]);
     }
 }

@@ -9,8 +9,8 @@
 //
 //   k_rev_rowsum   MultiplyMatrixVector  :398-410   x_B = B^-1 b (:89), u = B^-1 a_e (:150)
 //   k_rev_colsum   MultiplyVectorMatrix  :412-424   y = c_B B^-1 (:93); rc_j = c_j - y.A_j (:96-98)
-//   k_rev_enter    feasibility (:90-91) + entering fold (:105-121)
-//   k_rev_gather   GetColumn(A, e) / GetColumn(BInverse, k) (:149-151, :390-396)
+//   k_rev_enter    entering fold (:105-121), then GetColumn(A, e) / GetColumn(BInverse, k)
+//                  (:149-151, :390-396) in the same launch
 //   k_rev_ratio    ratio-test fold (:154-176), bookkeeping (:194-212), eta factors (:266-272)
 //   k_rev_update   UpdateBInverse = E * B^-1 (:264-275 via MultiplyMatrices :426-441), in place
 //   k_rev_extract  ExtractSolution (:277-287)
@@ -34,7 +34,7 @@ constexpr double kEps = 1e-9;  // RevisedPrimalSimplexSolver.cs:12
 // 16 lanes (one per row) walk the previous chunk out of LDS in order.  m/16 workgroups keep every
 // CU busy pulling its own 16 rows (a CU can only pull ~50 GB/s; one lane per row left 3/4 of the
 // chip idle).  `skip_if_slack`: the u = B^-1 a_e launch is a no-op when the entering variable is
-// a slack (then u is a column of B^-1, written by k_rev_gather).
+// a slack (then u is a column of B^-1, written by k_rev_enter).
 constexpr int kGRP = 16;   // operands fetched from LDS one group ahead of the add chain
 constexpr int kRB = 16;    // rows per workgroup
 constexpr int kKC = 256;   // columns per chunk (a chunk costs max(walk, one memory round trip): 128 was
@@ -44,7 +44,7 @@ constexpr int kKC = 256;   // columns per chunk (a chunk costs max(walk, one mem
 // 16..31 of the same wave walk the same rows against v2 (u = B^-1 a_e) -- the second walk rides in
 // the SIMD lanes the first leaves idle, so B^-1 is read once per iteration for both (the C# calls
 // MultiplyMatrixVector twice, :89 and :150; the sums and their order are the same).  v2 is skipped
-// when there is no entering variable or it is a slack (u is then a column of B^-1, k_rev_gather).
+// when there is no entering variable or it is a slack (u is then a column of B^-1, k_rev_enter).
 __global__ __launch_bounds__(256) void k_rev_rowsum(const double* __restrict__ M, int ld, int m,
                                                     const double* __restrict__ v,
                                                     double* __restrict__ out,
@@ -65,7 +65,9 @@ __global__ __launch_bounds__(256) void k_rev_rowsum(const double* __restrict__ M
     const int row0 = blockIdx.x * kRB;
     const int nchunk = (m + kKC - 1) / kKC;
     // staging map: kRB * kKC / 2 double2 per chunk, NQ per lane; a lane's double2 sit in the same
-    // two columns of NQ rows, so it needs ONE double2 of v (and of v2)
+    // two columns of NQ rows, so it needs ONE double2 of v (and of v2).  (Leaving the walking wave
+    // out of the staging, as k_rev_colsum does on B^-1, was slower here: 37 -> 41 us with 128
+    // staging lanes.)
     constexpr int HK = kKC / 2;           // double2 per row of the chunk
     constexpr int NQ = kRB * HK / 256;    // per lane
     constexpr int RS = 256 / HK;          // rows covered by one pass of the 256 lanes
@@ -176,32 +178,40 @@ __global__ __launch_bounds__(256) void k_rev_colsum(const double* __restrict__ M
     const int tid = threadIdx.x;
     const int j0 = blockIdx.x * CB;
     const int nchunk = (rows + RC - 1) / RC;
-    // staging map: RC * CB / 2 double2 per chunk, NQ per lane; CB / 2 double2 per row
-    constexpr int NQ = RC * CB / 2 / 256;
+    // staging map: RC * CB / 2 double2 per chunk, CB / 2 double2 per row, dealt over the NS staging
+    // lanes.  With one walking wave (CB = 16, the chain-bound case) that wave does NOT stage: its
+    // instruction stream is the chain, and the loads, multiplies and LDS writes of a chunk would
+    // sit between two walks.
+    constexpr int kStageBase = (CB == 16) ? 64 : 0;
+    constexpr int NS = 256 - kStageBase;
     constexpr int H = CB / 2;
+    constexpr int NQ = (RC * H + NS - 1) / NS;
+    const int sid = tid - kStageBase;
     double2 rm[NQ];
     double rv[NQ];
     auto load_chunk = [&](int i0) {
+        if (sid < 0) return;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            const int idx = tid + q * 256;
+            const int idx = sid + q * NS;
             const int r = idx / H, cc = (idx % H) * 2;
             const int gi = i0 + r;
-            rm[q] = (gi < rows && j0 + cc < ld)
+            rm[q] = (idx < RC * H && gi < rows && j0 + cc < ld)
                         ? *reinterpret_cast<const double2*>(M + (size_t)gi * ld + j0 + cc)
                         : make_double2(0.0, 0.0);
-            rv[q] = (gi < rows) ? v[gi] : 0.0;
+            rv[q] = (idx < RC * H && gi < rows) ? v[gi] : 0.0;
         }
     };
     auto store_chunk = [&](int buf) {
+        if (sid < 0) return;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            const int idx = tid + q * 256;
+            const int idx = sid + q * NS;
             const int r = idx / H, cc = (idx % H) * 2;
             double2 p;
             p.x = rv[q] * rm[q].x;  // v[i] * M[i, j] rounded ...
             p.y = rv[q] * rm[q].y;
-            *reinterpret_cast<double2*>(&sP[buf][r][cc]) = p;
+            if (idx < RC * H) *reinterpret_cast<double2*>(&sP[buf][r][cc]) = p;
         }
     };
     load_chunk(0);
@@ -275,7 +285,11 @@ __device__ __forceinline__ int block_min_int(int v, int* lds) {
 __global__ __launch_bounds__(1024) void k_rev_enter(const double* __restrict__ rcx,
                                                     const double* __restrict__ y,
                                                     const uint8_t* __restrict__ is_basic, int n,
-                                                    int m, RevState* st) {
+                                                    int m, RevState* st,
+                                                    const double* __restrict__ A, int lda,
+                                                    const double* __restrict__ Binv, int ldb,
+                                                    double* __restrict__ acol,
+                                                    double* __restrict__ u) {
     if (st->status != kRunning) return;
     const int tid = threadIdx.x;
     // (the feasibility test of :90-91, "optimal" and the pivot limit are decided in k_rev_ratio,
@@ -297,23 +311,14 @@ __global__ __launch_bounds__(1024) void k_rev_enter(const double* __restrict__ r
         },
         lds_i2, lds_v2);
     if (tid == 0) st->entering = cur;
-}
-
-// ------------------------------------------------------------------------------------------
-// GetColumn (:390-396): structural e -> acol = A[:, e] (input of u = B^-1 a_e);
-// slack e = n + k -> u = BInverse[:, k] directly (:151).
-__global__ __launch_bounds__(256) void k_rev_gather(const double* __restrict__ A, int lda,
-                                                    const double* __restrict__ Binv, int ldb,
-                                                    int n, int m, double* __restrict__ acol,
-                                                    double* __restrict__ u,
-                                                    const RevState* __restrict__ st) {
-    if (st->status != kRunning) return;
-    const int e = st->entering;
-    if (e < 0) return;  // no entering variable: k_rev_ratio will report the optimum
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
-    if (e < n) acol[i] = A[(size_t)i * lda + e];
-    else u[i] = Binv[(size_t)i * ldb + (e - n)];
+    // GetColumn (:390-396) rides the tail of this launch (it was a kernel of its own: 4.7 us plus a
+    // launch gap): structural e -> acol = A[:, e] (input of u = B^-1 a_e); slack e = n + k ->
+    // u = BInverse[:, k] directly (:151).  No entering variable: k_rev_ratio reports the optimum.
+    if (cur < 0) return;
+    for (int i = tid; i < m; i += blockDim.x) {
+        if (cur < n) acol[i] = A[(size_t)i * lda + cur];
+        else u[i] = Binv[(size_t)i * ldb + (cur - n)];
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -896,9 +901,7 @@ void rev_launch_iteration(lpr_revised* s, bool snapshot) {
     hipLaunchKernelGGL((k_rev_colsum<kRC, kCBA>), dim3((n + kCBA - 1) / kCBA), dim3(256), (rev_colsum_lds<kRC, kCBA>()), st, s->A, s->lda, m,
                        n, s->y, s->c, s->rcx, 1, s->state);
     hipLaunchKernelGGL(k_rev_enter, dim3(1), dim3(1024), 0, st, s->rcx, s->y, s->is_basic, n, m,
-                       s->state);
-    hipLaunchKernelGGL(k_rev_gather, dim3((m + 255) / 256), dim3(256), 0, st, s->A, s->lda,
-                       s->Binv, s->ldb, n, m, s->acol, s->u, s->state);
+                       s->state, s->A, s->lda, s->Binv, s->ldb, s->acol, s->u);
     // x_B = B^-1 b (:89) and u = B^-1 a_e (:150; unless the entering variable is a slack) in one
     // pass over B^-1
     hipLaunchKernelGGL(k_rev_rowsum, dim3((m + kRB - 1) / kRB), dim3(256), rev_rowsum_lds(), st, s->Binv, s->ldb,
