@@ -45,6 +45,15 @@ constexpr int kOvNT = 256;      // threads per workgroup (heads and tiles)
 constexpr int kOvGroups = 64;   // head workgroups, upper bound
 constexpr unsigned kOvSpinMax = 1u << 22;
 constexpr int kOvTileRows = 32; // rows per sweep workgroup (TR of them in flight at a time)
+// ov_heads_rich: the unit of a hand-off is the WAVE, not the workgroup -- every wave publishes its
+// own partial once its own stores have drained and collects all G x kOvWPG of them itself: no LDS
+// combine, no workgroup barrier in a head (false: one partial per workgroup, four barriers per head)
+#ifndef LPR_OV_WAVE_HANDOFF
+#define LPR_OV_WAVE_HANDOFF 1
+#endif
+constexpr bool kOvWaveHandoff = LPR_OV_WAVE_HANDOFF != 0;
+constexpr int kOvWPG = kOvNT / 64;                  // waves per head workgroup
+constexpr int kOvParts = kOvGroups * kOvWPG;        // partial slots per bank
 
 struct OvCtl {
     int32_t status;    // kRunning or the final lpr_status
@@ -105,7 +114,7 @@ __global__ __launch_bounds__(1024) void k_ov_prologue(const double* __restrict__
     __shared__ int lds_i[16];
     const int tid = threadIdx.x, nt = blockDim.x;
     // the granule banks start from epoch 0 (the bank written below: its other workgroup slots)
-    for (int k = tid; k < 9 * kOvGroups; k += nt) gran_all[k] = 0ull;
+    for (int k = tid; k < 9 * kOvParts; k += nt) gran_all[k] = 0ull;
     for (int k = tid; k < kOvGroups; k += nt) xgran[k] = 0ull;
     if (tid < 4) bar[tid] = 0u;
     if (tid < 2) tileq[tid] = 0u;
@@ -129,7 +138,13 @@ __global__ __launch_bounds__(1024) void k_ov_prologue(const double* __restrict__
         const int i = (tid == 0) ? c.i : -1;
         bank[tid].v = v;
         bank[tid].i = i;
-        // the same partials as granules (ov_heads_rich), see gr_publish
+    }
+    // the same partials as granules (ov_heads_rich), see gr_publish: one per workgroup, or one per
+    // wave of every workgroup
+    const int nparts = kOvWaveHandoff ? G * kOvWPG : G;
+    if (tid < nparts) {
+        const double v = (tid == 0) ? c.v : 0.0;
+        const int i = (tid == 0) ? c.i : -1;
         const unsigned long long e = (unsigned long long)epoch << 32;
         gbank[tid * 3 + 0] = e | (unsigned)__double2loint(v);
         gbank[tid * 3 + 1] = e | (unsigned)__double2hiint(v);
@@ -617,6 +632,52 @@ __device__ __forceinline__ Cand gr_collect(const unsigned long long* base, int G
     return ov_wave_min(c);
 }
 
+// The same with one partial per WAVE (P = G x kOvWPG of them, P <= 256): every wave collects for
+// itself, a lane fetches the partials lane, lane + 64, ...
+__device__ __forceinline__ Cand gr_collect_waves(const unsigned long long* base, int P,
+                                                 unsigned epoch, double none, int* fail) {
+    const int lane = threadIdx.x & (kWave - 1);
+    Cand c;
+    c.v = none;
+    c.i = -1;
+    for (unsigned spins = 0;; ++spins) {
+        bool ok = true;
+        Cand acc;
+        acc.v = none;
+        acc.i = -1;
+        for (int p = lane; p < P; p += kWave) {
+            const unsigned long long a = __hip_atomic_load(base + p * 3 + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long b = __hip_atomic_load(base + p * 3 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long d = __hip_atomic_load(base + p * 3 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = ok && (unsigned)(a >> 32) == epoch && (unsigned)(b >> 32) == epoch &&
+                 (unsigned)(d >> 32) == epoch;
+            Cand o;
+            o.v = __hiloint2double((int)(unsigned)b, (int)(unsigned)a);
+            o.i = (int)(unsigned)d;
+            acc = cand_min(acc, o);
+        }
+        if (__all(ok)) {
+            c = acc;
+            break;
+        }
+        if (spins > kOvSpinMax) {
+            *fail = 1;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return ov_wave_min(c);
+}
+
+// ... and the wave's side of it: reduce, wait for the wave's OWN stores of the phase, publish.  A
+// collector that has seen all P partials of an epoch knows that every wave's stores have landed.
+__device__ __forceinline__ void ov_publish_wave_min(Cand c, unsigned long long* g3, unsigned epoch,
+                                                    bool l2) {
+    c = ov_wave_min(c);
+    __builtin_amdgcn_s_waitcnt(0);
+    if ((threadIdx.x & (kWave - 1)) == 0) gr_publish(g3, epoch, c.v, c.i, l2);
+}
+
 // One phase of a head ends: every wave reduces its lanes' candidates and leaves the result in its
 // LDS slot, waits until its own stores of the phase have been acknowledged, and meets the others at
 // ONE workgroup barrier; then lane 0 combines the slots and publishes the workgroup's partial.
@@ -821,20 +882,32 @@ __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, i
             double* colq = fcolN + (size_t)(q - 1) * Rp;
 
             // ---- entering column (:152-167) from the partials of the previous head ----
-            if (tid < kWave) {  // wave 0 collects the G partials (this is also the barrier)
+            int e;
+            if (kOvWaveHandoff) {  // every wave collects the G x kOvWPG partials (the barrier)
                 int fail = 0;
-                const Cand zc = gr_collect(B.gran + (size_t)(pidx & 1) * 3 * kOvGroups, G,
-                                           (unsigned)(2 * pidx + 1), 0.0, &fail);
-                if (tid == 0) {
-                    s_pick[0] = zc.i;
-                    s_pick[1] = fail;
+                const Cand zc = gr_collect_waves(B.gran + (size_t)(pidx & 1) * 3 * kOvParts,
+                                                 G * kOvWPG, (unsigned)(2 * pidx + 1), 0.0, &fail);
+                e = zc.i;
+                if (fail) {
+                    err = 1;
+                    break;
                 }
-            }
-            __syncthreads();
-            const int e = s_pick[0];
-            if (s_pick[1]) {
-                err = 1;
-                break;
+            } else {
+                if (tid < kWave) {  // wave 0 collects the G partials (this is also the barrier)
+                    int fail = 0;
+                    const Cand zc = gr_collect(B.gran + (size_t)(pidx & 1) * 3 * kOvParts, G,
+                                               (unsigned)(2 * pidx + 1), 0.0, &fail);
+                    if (tid == 0) {
+                        s_pick[0] = zc.i;
+                        s_pick[1] = fail;
+                    }
+                }
+                __syncthreads();
+                e = s_pick[0];
+                if (s_pick[1]) {
+                    err = 1;
+                    break;
+                }
             }
             OV_STAMP(q, 1);  // entering column known
             if (e < 0) {
@@ -925,23 +998,38 @@ __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, i
             // has drained; then wave 0 collects the G partials: the leaving row (:169-191)
             OV_STAMP(q, 4);
             OV_STAMP(q, 5);
-            ov_publish_min(rc, lds_v, lds_i, B.gran + (size_t)(2 * kOvGroups + g) * 3,
-                           (unsigned)(2 * pidx + 2), l2);
-            OV_STAMP(q, 6);  // column slice drained, partial published
-            if (tid < kWave) {
+            int r;
+            if (kOvWaveHandoff) {
+                ov_publish_wave_min(rc, B.gran + ((size_t)2 * kOvParts + g * kOvWPG + tid / kWave) * 3,
+                                    (unsigned)(2 * pidx + 2), l2);
+                OV_STAMP(q, 6);  // column slice drained, partial published
                 int fail = 0;
-                const Cand rr = gr_collect(B.gran + (size_t)2 * 3 * kOvGroups, G,
-                                           (unsigned)(2 * pidx + 2), DBL_MAX, &fail);
-                if (tid == 0) {
-                    s_pick[0] = rr.i;
-                    s_pick[1] = fail;
+                const Cand rr = gr_collect_waves(B.gran + (size_t)2 * 3 * kOvParts, G * kOvWPG,
+                                                 (unsigned)(2 * pidx + 2), DBL_MAX, &fail);
+                r = rr.i;
+                if (fail) {
+                    err = 1;
+                    break;
                 }
-            }
-            __syncthreads();
-            const int r = s_pick[0];
-            if (s_pick[1]) {
-                err = 1;
-                break;
+            } else {
+                ov_publish_min(rc, lds_v, lds_i, B.gran + (size_t)(2 * kOvParts + g) * 3,
+                               (unsigned)(2 * pidx + 2), l2);
+                OV_STAMP(q, 6);  // column slice drained, partial published
+                if (tid < kWave) {
+                    int fail = 0;
+                    const Cand rr = gr_collect(B.gran + (size_t)2 * 3 * kOvParts, G,
+                                               (unsigned)(2 * pidx + 2), DBL_MAX, &fail);
+                    if (tid == 0) {
+                        s_pick[0] = rr.i;
+                        s_pick[1] = fail;
+                    }
+                }
+                __syncthreads();
+                r = s_pick[0];
+                if (s_pick[1]) {
+                    err = 1;
+                    break;
+                }
             }
             OV_STAMP(q, 7);  // leaving row known
             if (r < 0) {
@@ -1147,9 +1235,14 @@ __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, i
             // head is collected by the next launch, whose workgroups may sit on another XCD: that
             // one always goes through the memory side.
             OV_STAMP(q, 10);
-            ov_publish_min(n, lds_v, lds_i,
-                           B.gran + ((size_t)((pidx + 1) & 1) * kOvGroups + g) * 3,
-                           (unsigned)(2 * (pidx + 1) + 1), l2 && q < K);
+            if (kOvWaveHandoff)
+                ov_publish_wave_min(n, B.gran + ((size_t)((pidx + 1) & 1) * kOvParts + g * kOvWPG +
+                                                 tid / kWave) * 3,
+                                    (unsigned)(2 * (pidx + 1) + 1), l2 && q < K);
+            else
+                ov_publish_min(n, lds_v, lds_i,
+                               B.gran + ((size_t)((pidx + 1) & 1) * kOvParts + g) * 3,
+                               (unsigned)(2 * (pidx + 1) + 1), l2 && q < K);
             OV_STAMP(q, 11);  // row slice drained, partial published
         }
     }
@@ -1648,7 +1741,7 @@ int ov_ensure(lpr_tableau* t, bool second_buffer) {
     chk(hipMalloc(&c->b.bvec, (size_t)2 * c->Rp * D));
     chk(hipMalloc(&c->b.zparts, (size_t)2 * kOvGroups * sizeof(ZPart)));
     chk(hipMalloc(&c->b.rparts, (size_t)(3 * kOvGroups + 1) * sizeof(double)));
-    chk(hipMalloc(&c->b.gran, (size_t)9 * kOvGroups * sizeof(unsigned long long)));
+    chk(hipMalloc(&c->b.gran, (size_t)9 * kOvParts * sizeof(unsigned long long)));
     chk(hipMalloc(&c->b.xgran, (size_t)kOvGroups * sizeof(unsigned long long)));
     chk(hipMalloc(&c->b.dbg, kOvDbgWords * sizeof(unsigned long long)));
     chk(hipMalloc(&c->b.hx, 2 * sizeof(unsigned long long)));
@@ -1724,7 +1817,7 @@ int ov_begin(lpr_tableau* t, int64_t iter, int64_t max_iter) {
     hipLaunchKernelGGL(k_ov_prologue, dim3(1), dim3(1024), 0, s, t->T, t->ld, t->rows, t->cols,
                        c->b.zrow, c->b.bvec + (size_t)(iter & 1) * c->Rp,
                        c->b.zparts + (iter & 1) * kOvGroups, ov_groups(t),
-                       c->b.gran + (size_t)(iter & 1) * 3 * kOvGroups, (unsigned)(2 * iter + 1),
+                       c->b.gran + (size_t)(iter & 1) * 3 * kOvParts, (unsigned)(2 * iter + 1),
                        c->b.gran, c->b.xgran, c->b.bar, c->b.tileq, c->b.hx, c->b.sflag);
     LPR_HIP(hipGetLastError());
     return LPR_OK_OPTIMAL;
