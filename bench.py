@@ -157,7 +157,7 @@ def run_primal(args, D: Dist):
     # one pivot to learn how many pivots a step of the path chosen for this tableau applies
     probe = tab.solve(max_pivots=1, variant=args.variant, block=args.block)
     B = max(1, probe.block)
-    if B == 1 and args.block == 0 and args.variant == 0 and R * C * 8 <= (12 << 20):
+    if B == 1 and args.block == 0 and args.variant == 0 and R * C * 8 <= (1 << 20):
         # the single-launch path of small (cache-resident) tableaux has no per-kernel event
         # timing (asking for it would switch to another path): whole-job figures only
         timed = False
@@ -188,7 +188,7 @@ def run_primal(args, D: Dist):
     if D.rank == 0:
         value = D.world * K * B / dt_max
         two_stream = B > 1 and (args.variant & 0xff00) in (0, 0x3000) and R * C * 8 > (300 << 20)
-        if B == 1 and not timed and R * C * 8 <= (12 << 20):
+        if B == 1 and not timed and R * C * 8 <= (1 << 20):
             kname = ("k_pivot_fused (selection + rank-1 update in one launch; the tableau is "
                      "cache-resident: effective GB/s, not an HBM fraction)")
         elif B == 1:

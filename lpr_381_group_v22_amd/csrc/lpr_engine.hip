@@ -238,7 +238,11 @@ static int default_batch(const lpr_tableau* t) {
 
 // Small tableaux (<= kFusedBytes): one k_pivot_fused launch per pivot, ping-pong between T and
 // T2.  opts.variant == 0x7fff forces the two-kernel path (tests), 0x7ffe forces the fused one.
-static constexpr size_t kFusedBytes = (size_t)12 << 20;  // measured cross-over with the K-pivot path
+// (round 2, after the wave-granular hand-offs of the loop heads and the 8-row tiles of the small
+// in-place sweep, pivots/s K-pivot path vs this one: m = 256 (1.6 MB) 143.6 k vs 137.9 k, m = 320
+// 141.9 k vs 121.0 k, m = 512 137.7 k vs 99.7 k.  Below ~1 MB a solve is a few dozen pivots and the
+// start-up of the K-pivot path -- prologue, a fill and a drain step -- is what counts.)
+static constexpr size_t kFusedBytes = (size_t)1 << 20;
 
 static bool use_fused(const lpr_tableau* t, const lpr_solve_opts& o) {
     if (o.time_kernels) return false;

@@ -1,4 +1,4 @@
-// overlap_kernels.hip -- the primal path of tableaux above 12 MB: K pivots per sweep, decided by
+// overlap_kernels.hip -- the primal path of tableaux above 1 MB: K pivots per sweep, decided by
 // persistent "loop head" workgroups; on the largest tableaux the heads of the NEXT K pivots run
 // while the sweep of the current K is running.
 // (reference: LPR_381_Group_V22/Simplex/PrimalSimplexSolver.cs:102-211)
@@ -9,7 +9,7 @@
 //                              with a spin barrier between the two phases of a head.
 //   ov_tiles                   the sweep: 32-row x 256-double2 tiles.
 // and three ways of putting them on the device (lpr_engine.hip picks by tableau size):
-//   k_ov_heads + k_ov_sweep    heads, then the sweep in place (0x40tr; 12 MB .. 80 MB).
+//   k_ov_heads + k_ov_sweep    heads, then the sweep in place (0x40tr; 1 MB .. 80 MB).
 //   k_ov2_heads || k_ov2_sweep two kernels on two streams (0x30tr; above 80 MB): the sweep is out
 //                              of place (tableau buffer `cur` -> `cur ^ 1`), so while it runs the
 //                              buffer it reads is still the tableau BEFORE the block, and the heads
@@ -1387,7 +1387,7 @@ __device__ __forceinline__ void ov_rows_store(const ov_v2d (&x)[TR], ov_v2d* dst
 // launch's heads have said where they are (B.hx) -- the heads then run as fast as with nothing
 // beside them.  Wrong or missing hints cost time, never correctness: any workgroup may take any
 // tile.  `static_tile` >= 0: one given tile (the one-launch form k_ov_step has no queue).
-template <int TR, bool DB, bool INPLACE>
+template <int TR, bool DB, bool INPLACE, int TROWS = kOvTileRows>
 __device__ __forceinline__ void ov_one_tile(const OvBuffers& B, const OvCtl* ci,
                                             const double* __restrict__ fc,
                                             const ov_v2d* __restrict__ prow2, int tb, int ld,
@@ -1395,7 +1395,7 @@ __device__ __forceinline__ void ov_one_tile(const OvBuffers& B, const OvCtl* ci,
     typedef ov_v2d v2d;
     const int ld2 = ld >> 1;
     const int nct = (ld2 + kOvNT - 1) / kOvNT;
-    const int nrt = (R + kOvTileRows - 1) / kOvTileRows;
+    const int nrt = (R + TROWS - 1) / TROWS;
     if (LPR_OV_DIAG & 16) {  // workgroup b sits on XCD b % 8: give each XCD consecutive tiles
         const int per = (nct * nrt + 7) / 8;
         tb = (tb % 8) * per + tb / 8;
@@ -1424,10 +1424,10 @@ __device__ __forceinline__ void ov_one_tile(const OvBuffers& B, const OvCtl* ci,
         if (LPR_OV_DIAG & 2) p[s] = v2d{(double)c2, (double)s};
         else p[s] = prow2[(size_t)s * ld2 + c2];
     }
-    const int ibase = rt * kOvTileRows;
-    const int iend = min(R, ibase + kOvTileRows);
+    const int ibase = rt * TROWS;
+    const int iend = min(R, ibase + TROWS);
 
-    if (K == kOvMax && iend - ibase == kOvTileRows) {
+    if (K == kOvMax && iend - ibase == TROWS) {
         // rows of this tile that are pivot rows of the block, as a bit mask (wave-uniform)
         unsigned prmask = 0u;
 #pragma unroll
@@ -1442,11 +1442,11 @@ __device__ __forceinline__ void ov_one_tile(const OvBuffers& B, const OvCtl* ci,
             v2d xa[TR], xb[TR];
             ov_rows_load<TR, INPLACE>(xa, src, ld2);
 #pragma unroll 1
-            for (int j = 0; j < kOvTileRows; j += 2 * TR) {
+            for (int j = 0; j < TROWS; j += 2 * TR) {
                 ov_rows_load<TR, INPLACE>(xb, src + step, ld2);
                 ov_chunk<TR>(xa, p, fc + ibase + j, Rp);
                 ov_rows_store<TR, INPLACE>(xa, dst, ld2, prmask >> j);
-                if (j + 2 * TR < kOvTileRows) ov_rows_load<TR, INPLACE>(xa, src + 2 * step, ld2);
+                if (j + 2 * TR < TROWS) ov_rows_load<TR, INPLACE>(xa, src + 2 * step, ld2);
                 ov_chunk<TR>(xb, p, fc + ibase + j + TR, Rp);
                 ov_rows_store<TR, INPLACE>(xb, dst + step, ld2, prmask >> (j + TR));
                 src += 2 * step;
@@ -1454,7 +1454,7 @@ __device__ __forceinline__ void ov_one_tile(const OvBuffers& B, const OvCtl* ci,
             }
         } else {
 #pragma unroll 1
-            for (int j = 0; j < kOvTileRows; j += TR) {
+            for (int j = 0; j < TROWS; j += TR) {
                 v2d x[TR];
                 ov_rows_load<TR, INPLACE>(x, src, ld2);
                 ov_chunk<TR>(x, p, fc + ibase + j, Rp);
@@ -1530,12 +1530,13 @@ __device__ __forceinline__ void ov_one_tile(const OvBuffers& B, const OvCtl* ci,
 }
 
 // avoid: 0 = never leave an XCD to the heads, 1 = live word only (B.hx), 2 = hint + live word
-template <int TR, bool DB, bool INPLACE>
+template <int TR, bool DB, bool INPLACE, int TROWS = kOvTileRows>
 __device__ __forceinline__ void ov_tiles(const OvBuffers& B, const double* __restrict__ fcol,
                                          const double* __restrict__ prow, int ld, int R, int Rp,
                                          int G, int lp, int static_tile, int avoid,
                                          bool write_ctl = true, int sweeps_done = -1) {
-    static_assert(kOvTileRows % (2 * TR) == 0, "tile rows must be a multiple of two chunks");
+    static_assert(TROWS % TR == 0 && (!DB || TROWS % (2 * TR) == 0) && TROWS <= 32,
+                  "tile rows: a multiple of the chunks in flight, and one bit each in prmask");
     __shared__ int s_tile;
     const OvCtl* ci = B.ctl + lp;
     const int K = (ci->status == kRunning) ? ci->kdone : 0;
@@ -1573,11 +1574,11 @@ __device__ __forceinline__ void ov_tiles(const OvBuffers& B, const double* __res
     const ov_v2d* __restrict__ prow2 =
         reinterpret_cast<const ov_v2d*>(prow + (size_t)sa * kOvMax * ld);
     if (static_tile >= 0) {
-        ov_one_tile<TR, DB, INPLACE>(B, ci, fc, prow2, static_tile, ld, R, Rp, K, cur);
+        ov_one_tile<TR, DB, INPLACE, TROWS>(B, ci, fc, prow2, static_tile, ld, R, Rp, K, cur);
         return;
     }
     const int ld2 = ld >> 1;
-    const int ntiles = ((ld2 + kOvNT - 1) / kOvNT) * ((R + kOvTileRows - 1) / kOvTileRows);
+    const int ntiles = ((ld2 + kOvNT - 1) / kOvNT) * ((R + TROWS - 1) / TROWS);
     // do loop heads that stage a block run beside this launch, and where?
     const bool heads_beside = !INPLACE && avoid > 0 && ci->status == kRunning &&
                               ci->pending == kRunning;
@@ -1602,7 +1603,7 @@ __device__ __forceinline__ void ov_tiles(const OvBuffers& B, const double* __res
         const int tile = s_tile;
         __syncthreads();
         if (tile >= ntiles) return;
-        ov_one_tile<TR, DB, INPLACE>(B, ci, fc, prow2, tile, ld, R, Rp, K, cur);
+        ov_one_tile<TR, DB, INPLACE, TROWS>(B, ci, fc, prow2, tile, ld, R, Rp, K, cur);
     }
 }
 
@@ -1650,14 +1651,15 @@ __global__ __launch_bounds__(NT) void k_ov_heads(const OvBuffers B, int ld, int 
     ov_heads_rich<NT, STAMP>(B, ld, R, C, Rp, K, G, 0, true, spread, no_l2, -1);
 }
 
-template <int TR, bool DB>
+template <int TR, bool DB, int TROWS = kOvTileRows>
 __global__ __launch_bounds__(kOvNT) void k_ov_sweep(const OvBuffers B,
                                                     const double* __restrict__ fcol_ro,
                                                     const double* __restrict__ prow_ro, int ld,
                                                     int R, int Rp) {
     // nothing runs beside the in-place sweep: one workgroup per tile, dealt by the hardware (the
-    // queue's counter costs a burst of ~1000 atomics on one word at the start of every sweep)
-    ov_tiles<TR, DB, true>(B, fcol_ro, prow_ro, ld, R, Rp, 0, 1, (int)blockIdx.x, 0);
+    // queue's counter costs a burst of ~1000 atomics on one word at the start of every sweep).
+    // TROWS = 8: small tableaux, where 32-row tiles would leave most CUs without a tile
+    ov_tiles<TR, DB, true, TROWS>(B, fcol_ro, prow_ro, ld, R, Rp, 0, 1, (int)blockIdx.x, 0);
 }
 
 }  // namespace lpr
@@ -1876,6 +1878,15 @@ void ov_launch_sweep(lpr_tableau* t, int tr) {
     hipStream_t s = t->eng->stream;
     const int nct = (t->ld / 2 + kOvNT - 1) / kOvNT;
     const int nrt = (t->rows + kOvTileRows - 1) / kOvTileRows;
+    const int cus = t->eng->num_cus > 0 ? t->eng->num_cus : 256;
+    if (nct * nrt < 2 * cus && ov_tile_code(tr) == 0x08) {
+        // a small tableau: 32-row tiles would give fewer workgroups than CUs and the sweep is all
+        // latency (m = 512: 68 tiles, 30 us for 12.6 MB); 8-row tiles spread it over the chip
+        const int nrt8 = (t->rows + 7) / 8;
+        hipLaunchKernelGGL((k_ov_sweep<8, false, 8>), dim3(nct * nrt8), dim3(kOvNT), 0, s, c->b,
+                           c->b.fcol, c->b.prow, t->ld, t->rows, c->Rp);
+        return;
+    }
     const dim3 grid(nct * nrt), blk(kOvNT);
 #define LPR_OV_SWEEP(TR, DB)                                                                     \
     hipLaunchKernelGGL((k_ov_sweep<TR, DB>), grid, blk, 0, s, c->b, c->b.fcol, c->b.prow, t->ld,  \

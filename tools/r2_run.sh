@@ -20,12 +20,12 @@ for step in "$@"; do
     tests-all) run tests_all 1100 python -m pytest tests -m gpu -x -q ;;
     tests-rest) run tests_rest 1100 python -m pytest tests -m gpu -x -q --deselect tests/test_block_gpu.py --deselect tests/test_primal_gpu.py --deselect tests/test_cut_gpu.py ;;
     tests-rev) run tests_rev 900 python -m pytest tests/test_revised_gpu.py tests/test_program_gpu.py tests/test_configs_gpu.py -m gpu -x -q ;;
-    bench-m512) run bench_m512 300 python bench.py --m 512 --n 1024 --steps 2000 --warmup 200 ;;
+    bench-m512) run bench_m512 300 python bench.py --m 512 --n 1024 --steps 96 --warmup 8 ;;
     tests-bb) run tests_bb 900 python -m pytest tests/test_bb_gpu.py tests/test_configs_gpu.py -m gpu -x -q ;;
     bench-bb) run bench_bb 600 python bench.py --workload bb ;;
     bench-revised) run bench_revised 600 python bench.py --workload revised --steps 200 --warmup 16 ;;
     bench-configs)
-      run bench_m512 300 python bench.py --m 512 --n 1024 --steps 2000 --warmup 200
+      run bench_m512 300 python bench.py --m 512 --n 1024 --steps 96 --warmup 8
       run bench_m2048 300 python bench.py --m 2048 --n 2048 --steps 128 --warmup 16
       run bench_block1 300 python bench.py --block 1 --steps 256 --warmup 32
       run bench_sens 600 python bench.py --workload sens --steps 32 --warmup 2 ;;
