@@ -69,7 +69,8 @@ struct lpr_bb {
     double* info = nullptr;           // slot_cap x (nvars + 1): z, decision values
     double* h_info = nullptr;         // pinned
     int32_t* d_running = nullptr;     // number of slots still in kBBDual / kBBPrimal
-    int32_t* h_running = nullptr;     // pinned
+    int32_t* h_running = nullptr;     // pinned ([1]: last pivot step of the batch that found work)
+    int last_steps = 0;               // ... of the previous batch: sizes the next first batch
     // host-side results of lpr_bb_run
     struct Rec {
         int32_t parent, kind, depth, var, status;

@@ -30,7 +30,7 @@ void bb_launch_copy_in(lpr_bb* b, const double* src, int src_ld, int rows, int c
 void bb_launch_round(lpr_bb* b, int nslots, int rows_max, int clean);
 void bb_launch_node_info(lpr_bb* b, int count);
 void bb_launch_add_constraint(lpr_bb* b, int nslots, int nparents, int rows_max, int cols_max);
-void bb_launch_pivot_step(lpr_bb* b, int nslots, int rows_max, int cols_max);
+void bb_launch_pivot_step(lpr_bb* b, int nslots, int rows_max, int cols_max, int step_no);
 void bb_launch_select_only(lpr_bb* b, int nslots, int rows_max, int cols_max);
 
 // ---- .NET Framework rounding on the host (IsInteger :595-599 works on n values per node) ----
@@ -148,8 +148,8 @@ static int bb_ensure_slots(lpr_bb* b, int need) {
     LPR_HIP(hipMalloc(&b->info, S * (b->nvars + 1) * sizeof(double)));
     LPR_HIP(hipHostMalloc(&b->h_info, S * (b->nvars + 1) * sizeof(double)));
     if (!b->d_running) {
-        LPR_HIP(hipMalloc(&b->d_running, sizeof(int32_t)));
-        LPR_HIP(hipHostMalloc(&b->h_running, sizeof(int32_t)));
+        LPR_HIP(hipMalloc(&b->d_running, 2 * sizeof(int32_t)));
+        LPR_HIP(hipHostMalloc(&b->h_running, 2 * sizeof(int32_t)));
     }
     b->slot_cap = cap;
     return LPR_OK_OPTIMAL;
@@ -264,26 +264,34 @@ static int bb_expand(lpr_bb* b, int count, const int32_t* parent_ids, const int3
     }
     LPR_HIP(hipMemcpyAsync(b->d_slots, b->h_slots, (size_t)count * sizeof(BBSlot),
                            hipMemcpyHostToDevice, st));
-    *b->h_running = count;
-    LPR_HIP(hipMemcpyAsync(b->d_running, b->h_running, sizeof(int32_t), hipMemcpyHostToDevice,
+    b->h_running[0] = count;
+    b->h_running[1] = 0;
+    LPR_HIP(hipMemcpyAsync(b->d_running, b->h_running, 2 * sizeof(int32_t), hipMemcpyHostToDevice,
                            st));
     bb_launch_add_constraint(b, count, nparents, rows_max, cols_max);
 
     // DoDualSimplex: pivot steps until every child has left the running states
-    int poll = 4;  // pivot steps queued between polls of the running counter (grows to 32)
+    // Pivot steps queued between polls of the running counter.  A poll idles the device ~50 us; a
+    // step queued after the last child has finished still dispatches every workgroup of the batch
+    // (10-40 us at a wide level).  The children of one level need about as many steps as those of
+    // the level before (running[1] of that batch), so the first batch is sized by it; without a
+    // history 4, then doubling up to 32.
+    int poll = b->last_steps > 4 ? b->last_steps : 4;
+    int queued = 0;
     int64_t guard = 0;
     for (;;) {
         // k_bb_select and k_bb_update always run as a pair: a select that starts a pivot sets
         // do_update, and the NEXT select swaps cur/nxt on the strength of that flag
-        for (int k = 0; k < poll; ++k) bb_launch_pivot_step(b, count, rows_max, cols_max);
+        for (int k = 0; k < poll; ++k) bb_launch_pivot_step(b, count, rows_max, cols_max, ++queued);
         LPR_HIP(hipGetLastError());
-        LPR_HIP(hipMemcpyAsync(b->h_running, b->d_running, sizeof(int32_t), hipMemcpyDeviceToHost,
-                               st));
+        LPR_HIP(hipMemcpyAsync(b->h_running, b->d_running, 2 * sizeof(int32_t),
+                               hipMemcpyDeviceToHost, st));
         LPR_HIP(hipStreamSynchronize(st));
         b->prof.polls += 1;
         b->prof.steps += poll;
-        if (*b->h_running <= 0) break;
-        if (poll < 32) poll *= 2;
+        if (b->h_running[0] <= 0) break;
+        poll = (queued <= 4 && b->last_steps <= 4) ? 8 : 4;  // (then in fours: the tail is short)
+        if (b->last_steps <= 4 && queued >= 12) poll = queued < 32 ? queued : 32;
         if (++guard > (1 << 16)) {
             // the reference has no pivot cap either (a cycling LP spins for ever in the C#);
             // the engine gives up instead of hanging the stream
@@ -291,6 +299,7 @@ static int bb_expand(lpr_bb* b, int count, const int32_t* parent_ids, const int3
             return LPR_PIVOT_LIMIT;
         }
     }
+    b->last_steps = b->h_running[1];
     // the loop only ends when no slot is running; the select that finishes a slot leaves
     // do_update = 0, so every cur/nxt swap is settled here
     bb_launch_round(b, count, rows_max, 0);  // RoundAllTableaux(newTableaux) :1124 / :1187

@@ -313,7 +313,8 @@ __global__ __launch_bounds__(256) void k_bb_round(BBSlot* __restrict__ slots, in
 __global__ __launch_bounds__(1024) void k_bb_select(BBSlot* slots, double* __restrict__ rowbuf_all,
                                                     double* __restrict__ colbuf_all, int ld,
                                                     int rows_cap, int32_t* __restrict__ trace_all,
-                                                    int trace_cap, int32_t* running) {
+                                                    int trace_cap, int32_t* running,
+                                                    int step_no) {
     __shared__ double lds_v[16];
     __shared__ int lds_i[16];
     BBSlot* sp = &slots[blockIdx.x];
@@ -546,6 +547,9 @@ __global__ __launch_bounds__(1024) void k_bb_select(BBSlot* slots, double* __res
         sp->do_update = do_update;
         sp->trace_n = trace_n;
         if (old_state < kBBSolved && state >= kBBSolved) atomicSub(running, 1);
+        // running[1]: the last step of this batch that found a child still at work (the host sizes
+        // the first batch of the next level by it)
+        if (old_state < kBBSolved) atomicMax(running + 1, step_no);
     }
 }
 
@@ -668,11 +672,11 @@ void bb_launch_add_constraint(lpr_bb* b, int nslots, int nparents, int rows_max,
                        b->d_slots, b->ld, b->bflag, b->bkey, b->blist);
 }
 
-void bb_launch_pivot_step(lpr_bb* b, int nslots, int rows_max, int cols_max) {
+void bb_launch_pivot_step(lpr_bb* b, int nslots, int rows_max, int cols_max, int step_no) {
     hipStream_t st = b->eng->stream;
     const int threads = (rows_max > 256 || cols_max > 256) ? 1024 : 256;
     hipLaunchKernelGGL(k_bb_select, dim3(nslots), dim3(threads), 0, st, b->d_slots, b->rowbuf,
-                       b->colbuf, b->ld, b->rows_cap, b->trace, b->trace_cap, b->d_running);
+                       b->colbuf, b->ld, b->rows_cap, b->trace, b->trace_cap, b->d_running, step_no);
     constexpr int TR = 4;
     const int ld2 = align_up(cols_max, kLdAlign) / 2;
     hipLaunchKernelGGL((k_bb_update<TR>), dim3((ld2 + 255) / 256, (rows_max + TR - 1) / TR, nslots),
@@ -683,7 +687,7 @@ void bb_launch_select_only(lpr_bb* b, int nslots, int rows_max, int cols_max) {
     const int threads = (rows_max > 256 || cols_max > 256) ? 1024 : 256;
     hipLaunchKernelGGL(k_bb_select, dim3(nslots), dim3(threads), 0, b->eng->stream, b->d_slots,
                        b->rowbuf, b->colbuf, b->ld, b->rows_cap, b->trace, b->trace_cap,
-                       b->d_running);
+                       b->d_running, 0);
 }
 
 }  // namespace lpr

@@ -839,14 +839,23 @@ __global__ __launch_bounds__(256, 2) void k_rev_gemm(const double* __restrict__ 
 // launchers
 
 // dynamic LDS of k_rev_rowsum: two product tiles x two buffers
+// (the attribute belongs to the device the call is made on: asked once per device, not per process)
+static bool rev_first_ask(unsigned long long (&mask)[4]) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 256) return true;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (mask[dev >> 6] & bit) return false;
+    mask[dev >> 6] |= bit;
+    return true;
+}
+
 static size_t rev_rowsum_lds() {
     constexpr size_t bytes = (size_t)4 * kRB * (kKC + kGRP + 2) * sizeof(double);
-    static bool asked = false;
-    if (!asked) {
+    static unsigned long long asked[4] = {0, 0, 0, 0};
+    if (rev_first_ask(asked))
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rev_rowsum),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        asked = true;
-    }
     return bytes;
 }
 
@@ -854,12 +863,10 @@ static size_t rev_rowsum_lds() {
 template <int RC, int CB>
 static size_t rev_colsum_lds() {
     constexpr size_t bytes = (size_t)(2 * (RC + kGRP) * CB) * sizeof(double);
-    static bool asked = false;
-    if (!asked) {
+    static unsigned long long asked[4] = {0, 0, 0, 0};
+    if (rev_first_ask(asked))
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rev_colsum<RC, CB>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        asked = true;
-    }
     return bytes;
 }
 
