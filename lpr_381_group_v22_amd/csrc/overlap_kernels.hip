@@ -202,6 +202,28 @@ __device__ __forceinline__ double ov_rl(double v, int k) {
 // (value, index) lexicographic minimum over the 64 lanes of a wave, in every lane, with DPP moves
 // (row-local permutes, then the two row broadcasts of gfx9) instead of six rounds of ds_bpermute:
 // the operation is associative and commutative, so the order of combination does not matter.
+// bit t of mask ? a : b on the bit patterns, a wave-uniform (it comes out of v_readlane): one
+// v_bfe_i32 + two v_bfi_b32 with a read straight from its SGPRs, instead of an and, a compare, two
+// moves of a into VGPRs and two v_cndmask (the chains are issue-bound: 12 -> 7 instructions per
+// step).  Inline asm: written as C the bit operations are folded back into select(compare).
+__device__ __forceinline__ double ov_bitsel(unsigned mask, int t, double a, double b) {
+    int m, lo, hi;
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(mask), "s"(t));
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(lo) : "v"(m), "s"(__double2loint(a)), "v"(__double2loint(b)));
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(hi) : "v"(m), "s"(__double2hiint(a)), "v"(__double2hiint(b)));
+    return __hiloint2double(hi, lo);
+}
+
+// cand_min without branches (the early returns of cand_min compile to exec-masked branches around
+// every one of the six DPP stages: ~25 instructions each, four reductions per head)
+__device__ __forceinline__ Cand ov_cand_min_sel(Cand a, Cand b) {
+    const bool take = (b.i >= 0) & ((a.i < 0) | (b.v < a.v) | ((b.v == a.v) & (b.i < a.i)));
+    Cand r;
+    r.v = take ? b.v : a.v;
+    r.i = take ? b.i : a.i;
+    return r;
+}
+
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ Cand ov_dpp_min(Cand c) {
     Cand o;
@@ -210,18 +232,45 @@ __device__ __forceinline__ Cand ov_dpp_min(Cand c) {
     const int ohi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
     o.i = __builtin_amdgcn_update_dpp(c.i, c.i, CTRL, ROW_MASK, 0xf, false);
     o.v = __hiloint2double(ohi, olo);
-    return cand_min(c, o);
+    return ov_cand_min_sel(c, o);
+}
+// Wave-wide lexicographic minimum of (value, index), index < 0 = no candidate; the result in every
+// lane.  Two plain reductions instead of one on pairs (six stages of ~20 instructions each): the
+// minimum VALUE over the candidates (two DPP moves + v_min_f64 per stage), then the minimum INDEX
+// over the lanes that hold it (v_min_i32 with a DPP operand).  Candidates are never NaN (a ratio is
+// finite and >= 0, a Z-row entry passed a `<` test), -0.0 == +0.0 ties go to the lower index as in
+// cand_min, and the value returned when there is no candidate is not used by any caller.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double ov_dpp_fmin(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int olo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+    const int ohi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+    return fmin(v, __hiloint2double(ohi, olo));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int ov_dpp_imin(int i) {
+    return min(i, __builtin_amdgcn_update_dpp(i, i, CTRL, ROW_MASK, 0xf, false));
 }
 __device__ __forceinline__ Cand ov_wave_min(Cand c) {
-    c = ov_dpp_min<0xB1, 0xf>(c);   // quad_perm [1,0,3,2]
-    c = ov_dpp_min<0x4E, 0xf>(c);   // quad_perm [2,3,0,1]
-    c = ov_dpp_min<0x141, 0xf>(c);  // row_half_mirror
-    c = ov_dpp_min<0x140, 0xf>(c);  // row_mirror: every row of 16 holds its minimum
-    c = ov_dpp_min<0x142, 0xa>(c);  // row_bcast15 into rows 1 and 3
-    c = ov_dpp_min<0x143, 0xc>(c);  // row_bcast31 into rows 2 and 3: lane 63 holds the minimum
+    double v = (c.i >= 0) ? c.v : INFINITY;
+    v = ov_dpp_fmin<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+    v = ov_dpp_fmin<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+    v = ov_dpp_fmin<0x141, 0xf>(v);  // row_half_mirror
+    v = ov_dpp_fmin<0x140, 0xf>(v);  // row_mirror: every row of 16 holds its minimum
+    v = ov_dpp_fmin<0x142, 0xa>(v);  // row_bcast15 into rows 1 and 3
+    v = ov_dpp_fmin<0x143, 0xc>(v);  // row_bcast31 into rows 2 and 3: lane 63 holds the minimum
+    const double vmin = ov_rl(v, 63);
+    int i = (c.i >= 0 && c.v == vmin) ? c.i : INT_MAX;
+    i = ov_dpp_imin<0xB1, 0xf>(i);
+    i = ov_dpp_imin<0x4E, 0xf>(i);
+    i = ov_dpp_imin<0x141, 0xf>(i);
+    i = ov_dpp_imin<0x140, 0xf>(i);
+    i = ov_dpp_imin<0x142, 0xa>(i);
+    i = ov_dpp_imin<0x143, 0xc>(i);
+    const int imin = __builtin_amdgcn_readlane(i, 63);
     Cand r;
-    r.v = ov_rl(c.v, 63);
-    r.i = __builtin_amdgcn_readlane(c.i, 63);
+    r.v = vmin;
+    r.i = (imin == INT_MAX) ? -1 : imin;
     return r;
 }
 
@@ -654,7 +703,7 @@ __device__ __forceinline__ Cand gr_collect_waves(const unsigned long long* base,
             Cand o;
             o.v = __hiloint2double((int)(unsigned)b, (int)(unsigned)a);
             o.i = (int)(unsigned)d;
-            acc = cand_min(acc, o);
+            acc = ov_cand_min_sel(acc, o);
         }
         if (__all(ok)) {
             c = acc;
@@ -933,14 +982,14 @@ __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, i
                 const double pt = ov_rl(pv, t);
                 const double prod = fA[t] * pt;
                 const double d = cq - prod;
-                cq = ((maskA >> t) & 1u) ? pt : d;  // i_first == rA[t]: the pivot row
+                cq = ov_bitsel(maskA, t, pt, d);  // i_first == rA[t]: the pivot row keeps p_t[e]
             }
 #pragma unroll
             for (int t = 0; t < kOvMax; ++t) {  // through this block's earlier pivots
                 const double pt = ov_rl(pv, kOvMax + t);
                 const double prod = myf[t] * pt;
                 const double d = cq - prod;
-                cq = ((maskN >> t) & 1u) ? pt : d;
+                cq = ov_bitsel(maskN, t, pt, d);
             }
 #pragma unroll
             for (int t = 0; t < kOvMax; ++t)
