@@ -44,7 +44,10 @@ constexpr int kOvMax = 16;      // pivots per block, upper bound
 constexpr int kOvNT = 256;      // threads per workgroup (heads and tiles)
 constexpr int kOvGroups = 64;   // head workgroups, upper bound
 constexpr unsigned kOvSpinMax = 1u << 22;
-constexpr int kOvTileRows = 32; // rows per sweep workgroup (TR of them in flight at a time)
+#ifndef LPR_OV_TILE_ROWS
+#define LPR_OV_TILE_ROWS 32  // (tools/sweep_bench.hip overrides it)
+#endif
+constexpr int kOvTileRows = LPR_OV_TILE_ROWS;  // rows per sweep workgroup (TR in flight at a time)
 // ov_heads_rich: the unit of a hand-off is the WAVE, not the workgroup -- every wave publishes its
 // own partial once its own stores have drained and collects all G x kOvWPG of them itself: no LDS
 // combine, no workgroup barrier in a head (false: one partial per workgroup, four barriers per head)
