@@ -164,14 +164,15 @@ def run_primal(args, D: Dist):
     if W > 0:
         # warm-up in the timed region's own mode (the engine creates its HIP events on first use:
         # ~10 us each, which is not pivot time); the statistics below are differences
-        res = tab.solve(max_pivots=W * B, time_kernels=timed, variant=args.variant,
-                        block=args.block)
+        res = tab.solve(max_pivots=W * B, time_kernels=(args.time_stride if timed else 0),
+                        variant=args.variant, block=args.block)
         if res.pivots != W * B:
             raise SystemExit(f"warm-up ended after {res.pivots} pivots (status {res.status})")
     k0, s0 = tab.kernel_stats(), tab.step_stats()
     D.barrier(eng)
     t0 = time.perf_counter()
-    res = tab.solve(max_pivots=K * B, time_kernels=timed, variant=args.variant, block=args.block)
+    res = tab.solve(max_pivots=K * B, time_kernels=(args.time_stride if timed else 0),
+                    variant=args.variant, block=args.block)
     D.barrier(eng)
     dt = time.perf_counter() - t0
     if res.pivots != K * B or res.block != B:
@@ -211,8 +212,11 @@ def run_primal(args, D: Dist):
                          # (profiles/r02_sweep_floor_probe.jsonl): what an out-of-place copy achieves
                          "frac_vs_measured_copy_5180": round(achieved / 5180.0, 4),
                          "avg_launch_ms": round(kern_ms, 6), "launches": launches,
-                         "event_sampling": ("every sweep launch of the timed region that applied "
-                                            "a full block" if B > 1 else
+                         "event_sampling": ((("every sweep launch" if args.time_stride <= 1 else
+                                              f"one sweep launch in {args.time_stride}") +
+                                             " of the timed region that applied a full block "
+                                             "(two event records per step on the sweep's stream "
+                                             "cost the pipeline ~3 %)") if B > 1 else
                                             "every 4th update launch of the timed region")})
         else:
             roof["note_timing"] = "no launch of the timed region was bracketed by events"
@@ -558,6 +562,8 @@ def main() -> int:
                     help="pivots of the CPU baseline sample (-1: sized for ~15 s, 0: skip)")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="replay captured graphs instead of eager launches with HIP events")
+    ap.add_argument("--time-stride", type=int, default=4,
+                    help="K-pivot paths: bracket every n-th sweep launch with HIP events (1: all)")
     ap.add_argument("--bb-vars", type=int, default=512)
     ap.add_argument("--bb-cons", type=int, default=64)
     ap.add_argument("--bb-levels", type=int, default=9)

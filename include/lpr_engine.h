@@ -113,7 +113,9 @@ typedef struct lpr_solve_opts {
     int32_t time_kernels;  /* != 0: launch eagerly and bracket rank-1 update / sweep launches with
                               HIP events on the engine stream (every sweep on the K-pivot paths,
                               one update in four on the one-pivot path); read back with
-                              lpr_tableau_kernel_stats / lpr_tableau_step_stats */
+                              lpr_tableau_kernel_stats / lpr_tableau_step_stats  On the K-pivot paths a value n > 1 brackets every
+                              n-th step only (the events sit on the sweep's stream: two per step
+                              cost the two-stream pipeline ~3 %). */
     int32_t batch;         /* pivots queued between host polls of the device status word (0: auto) */
     int32_t variant;       /* kernel variant (0: auto); for tuning and tests only, same bits.  Low 16
                               bits: path + sweep tile (0x30tr two-stream overlap, 0x40tr heads then

@@ -498,6 +498,9 @@ static int solve_overlapped(lpr_tableau* t, const lpr_solve_opts& o, int K, int 
     int rc = ov_ensure(t, overlap);
     if (rc != LPR_OK_OPTIMAL) return rc;
     const bool timed = o.time_kernels != 0;
+    // opts.time_kernels = n > 1: events around every n-th step only (two event records per step
+    // cost the two-stream pipeline ~3 % -- they sit on the sweep's stream, on the critical cycle)
+    const int tstride = o.time_kernels > 1 ? (o.time_kernels < 16 ? o.time_kernels : 16) : 1;
     // steps between host polls: about 5 ms of device work (a step = one sweep at ~5 TB/s, or K loop
     // heads at ~8 us, whichever is longer); a poll costs the device ~0.1 ms of idling
     int nlaunch;
@@ -555,17 +558,18 @@ static int solve_overlapped(lpr_tableau* t, const lpr_solve_opts& o, int K, int 
         }
         for (int k = 0; k < nb; ++k, ++step) {
             const int lp = (int)(step & 1);
+            const bool tk = timed && (k % tstride == 0);
             if (two_streams) {
-                rc = ov2_launch_step(t, K, tr, lp, hflags, timed ? t->ev[2 * k] : nullptr,
-                                     timed ? t->ev[2 * k + 1] : nullptr);
+                rc = ov2_launch_step(t, K, tr, lp, hflags, tk ? t->ev[2 * k] : nullptr,
+                                     tk ? t->ev[2 * k + 1] : nullptr);
                 if (rc != LPR_OK_OPTIMAL) return rc;
                 continue;
             }
             if (!overlap) ov_launch_heads(t, K, hflags);
-            if (timed) LPR_HIP(hipEventRecord(t->ev[2 * k], s));
+            if (tk) LPR_HIP(hipEventRecord(t->ev[2 * k], s));
             if (overlap) ov_launch_step(t, K, tr, lp);
             else ov_launch_sweep(t, tr);
-            if (timed) LPR_HIP(hipEventRecord(t->ev[2 * k + 1], s));
+            if (tk) LPR_HIP(hipEventRecord(t->ev[2 * k + 1], s));
         }
         if (two_streams) {
             rc = ov2_join(t);
@@ -591,15 +595,21 @@ static int solve_overlapped(lpr_tableau* t, const lpr_solve_opts& o, int K, int 
             // one partial block and idle steps
             const int64_t full_now = (pl.applied - start_iter) / K - swept_full;
             const int first = (step == nb && overlap) ? 1 : 0;
-            for (int k = first; k < nb && k < first + full_now; ++k) {
+            for (int k = 0; k < nb && k < first + full_now; k += tstride) {
+                if (k < first) continue;  // (the sampled steps are the multiples of tstride)
                 float ms = 0.f;
                 LPR_HIP(hipEventElapsedTime(&ms, t->ev[2 * k], t->ev[2 * k + 1]));
                 t->timed_total_ms += ms;
                 t->timed_launches += 1;
-                float st = 0.f;
-                LPR_HIP(hipEventElapsedTime(&st, t->ev[2 * k], t->ev[2 * k + 2]));
-                t->timed_step_ms += st;
-                t->timed_steps += 1;
+                // start of this step to the start of the next SAMPLED one (or the closing event):
+                // that many steps, all of them full as long as they lie before first + full_now
+                const int kn = (k + tstride < nb) ? k + tstride : nb;
+                if (kn <= first + full_now) {
+                    float st = 0.f;
+                    LPR_HIP(hipEventElapsedTime(&st, t->ev[2 * k], t->ev[2 * kn]));
+                    t->timed_step_ms += st;
+                    t->timed_steps += kn - k;
+                }
             }
             swept_full += full_now;
         }

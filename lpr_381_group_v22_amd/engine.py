@@ -124,7 +124,7 @@ class Tableau:
     def solve(self, max_pivots: int = 0, time_kernels: bool = False, batch: int = 0,
               variant: int = 0, block: int = 0) -> N.SolveResult:
         """block: pivots decided ahead and applied per sweep on large tableaux (0 auto, 1..8)."""
-        opts = N.SolveOpts(max_pivots=max_pivots, time_kernels=1 if time_kernels else 0,
+        opts = N.SolveOpts(max_pivots=max_pivots, time_kernels=int(time_kernels),
                            batch=batch, variant=variant, block=block)
         res = N.SolveResult()
         N.check(N.lib.lpr_primal_solve(self._h, C.byref(opts), C.byref(res)), "lpr_primal_solve")

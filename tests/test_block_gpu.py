@@ -363,6 +363,25 @@ def test_mid_size_default_path_vs_oracle(engine, oracle, m, n):
     tab.destroy()
 
 
+def test_event_sampling_stride(engine, oracle):
+    """opts.time_kernels = 4 brackets one step in four of the two-stream path: a call of 10 full
+    blocks is 11 steps (the first only decides); steps 4 and 8 are sampled, the step windows run
+    to the next sampled step / the closing event.  Same bits as an untimed solve."""
+    from lpr_381_group_v22_amd import Tableau
+    m, n = 2048, 4096
+    T, basis = oracle.gen_dense_tableau(m, n, 5)
+    st, piv, log = oracle.primal_solve(T, basis, 160)
+    tab = Tableau.synthetic(engine, m, n, 5)
+    res = tab.solve(max_pivots=160, time_kernels=4)
+    assert res.status == st and res.pivots == piv == 160 and res.block == 16
+    launches, total_ms, avg_ms = tab.kernel_stats()
+    steps, step_ms = tab.step_stats()
+    assert launches == 2 and steps == 7 and 0 < avg_ms and total_ms < step_ms
+    assert tab.pivot_log().tolist() == log.tolist()
+    assert tab.read().tobytes() == T.tobytes()
+    tab.destroy()
+
+
 def test_north_star_size_ragged_legs_vs_oracle(engine, oracle):
     """The same size in legs that cut blocks (1 + 37 + 32 pivots, the bench's probe / warm-up /
     timed pattern) with kernel timing on: the tableau after 70 pivots equals the oracle's."""
