@@ -215,8 +215,8 @@ def run_primal(args, D: Dist):
                          "event_sampling": ((("every sweep launch" if args.time_stride <= 1 else
                                               f"one sweep launch in {args.time_stride}") +
                                              " of the timed region that applied a full block "
-                                             "(two event records per step on the sweep's stream "
-                                             "cost the pipeline ~3 %)") if B > 1 else
+                                             "(start / stop events of the launch itself; "
+                                             "sampling every launch costs ~1 % more)") if B > 1 else
                                             "every 4th update launch of the timed region")})
         else:
             roof["note_timing"] = "no launch of the timed region was bracketed by events"
@@ -562,7 +562,7 @@ def main() -> int:
                     help="pivots of the CPU baseline sample (-1: sized for ~15 s, 0: skip)")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="replay captured graphs instead of eager launches with HIP events")
-    ap.add_argument("--time-stride", type=int, default=4,
+    ap.add_argument("--time-stride", type=int, default=2,
                     help="K-pivot paths: bracket every n-th sweep launch with HIP events (1: all)")
     ap.add_argument("--bb-vars", type=int, default=512)
     ap.add_argument("--bb-cons", type=int, default=64)

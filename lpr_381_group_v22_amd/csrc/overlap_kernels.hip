@@ -27,6 +27,8 @@
 
 #include <new>
 
+#include <hip/hip_ext.h>
+
 #pragma clang fp contract(off)
 
 // tools/sweep_bench.hip compiles this file with LPR_OV_KERNELS_ONLY and LPR_OV_DIAG bits to take
@@ -1730,6 +1732,7 @@ struct lpr_overlap_ctx {
     hipEvent_t ev_h[2] = {nullptr, nullptr}, ev_s[2] = {nullptr, nullptr};
     int ev_idx = 0;
     int steps = 0;                  // launch pairs queued by the current solve call
+    hipEvent_t last_sweep = nullptr;  // the event that marks the latest sweep of the call as done
 };
 
 namespace lpr {
@@ -1971,6 +1974,7 @@ int ov2_begin(lpr_tableau* t) {
     c->steps = 0;
     LPR_HIP(hipEventRecord(c->ev_s[1], t->eng->stream));
     LPR_HIP(hipEventRecord(c->ev_h[1], c->hstream));
+    c->last_sweep = c->ev_s[1];
     LPR_HIP(hipStreamWaitEvent(c->hstream, c->ev_s[1], 0));
     return LPR_OK_OPTIMAL;
 }
@@ -1988,19 +1992,22 @@ int ov2_launch_step(lpr_tableau* t, int K, int tr, int lp, int flags, hipEvent_t
     // so it is opt-in.
     const bool by_event = (flags & 32) == 0;
     const int wait_sweeps = by_event ? -1 : c->steps;
-    if (by_event) LPR_HIP(hipStreamWaitEvent(H, c->ev_s[prev], 0));
+    // The events that order the two streams (and the ones that time a sampled step) are the
+    // completion signals of the kernels themselves (hipExtLaunchKernelGGL's stop event): a separate
+    // hipEventRecord is a packet of its own on the stream, ~3 us each on the critical cycle.
+    if (by_event) LPR_HIP(hipStreamWaitEvent(H, c->last_sweep, 0));
     LPR_HIP(hipStreamWaitEvent(S, c->ev_h[prev], 0));
-    if (ev_start) LPR_HIP(hipEventRecord(ev_start, S));  // both kernels of the previous step done
     const int G = ov_groups(t);
     const int spread = ov_spread(G, flags);
     const int no_l2 = (flags & 6) ? 1 : 0;
     if (flags & 1)
-        hipLaunchKernelGGL((k_ov2_heads<kOvNT, true>), dim3(G * spread), dim3(kOvNT), 0, H, c->b,
-                           t->ld, t->rows, t->cols, c->Rp, K, G, lp, spread, no_l2, wait_sweeps);
+        hipExtLaunchKernelGGL((k_ov2_heads<kOvNT, true>), dim3(G * spread), dim3(kOvNT), 0, H,
+                              nullptr, c->ev_h[cur], 0, c->b, t->ld, t->rows, t->cols, c->Rp, K, G,
+                              lp, spread, no_l2, wait_sweeps);
     else
-        hipLaunchKernelGGL((k_ov2_heads<kOvNT, false>), dim3(G * spread), dim3(kOvNT), 0, H, c->b,
-                           t->ld, t->rows, t->cols, c->Rp, K, G, lp, spread, no_l2, wait_sweeps);
-    LPR_HIP(hipEventRecord(c->ev_h[cur], H));
+        hipExtLaunchKernelGGL((k_ov2_heads<kOvNT, false>), dim3(G * spread), dim3(kOvNT), 0, H,
+                              nullptr, c->ev_h[cur], 0, c->b, t->ld, t->rows, t->cols, c->Rp, K, G,
+                              lp, spread, no_l2, wait_sweeps);
     const int nct = (t->ld / 2 + kOvNT - 1) / kOvNT;
     const int nrt = (t->rows + kOvTileRows - 1) / kOvTileRows;
     const dim3 grid(ov_sweep_grid(t, nct * nrt)), blk(kOvNT);
@@ -2008,9 +2015,12 @@ int ov2_launch_step(lpr_tableau* t, int K, int tr, int lp, int flags, hipEvent_t
     // word, 1 = by this launch's word only, 0 = never (flags 8 / 16; nothing to leave when the
     // heads are not confined to one XCD)
     const int avoid = (flags & (2 | 4 | 8)) ? 0 : ((flags & 16) ? 1 : 2);
-#define LPR_OV2_SWEEP(TR, DB)                                                                    \
-    hipLaunchKernelGGL((k_ov2_sweep<TR, DB>), grid, blk, 0, S, c->b, c->b.fcol, c->b.prow, t->ld, \
-                       t->rows, c->Rp, lp, avoid, by_event ? 1 : 0, by_event ? -1 : c->steps)
+    // a sampled step: its stop event is the timing event (start = the kernel's own start)
+    hipEvent_t sweep_done = ev_stop ? ev_stop : c->ev_s[cur];
+#define LPR_OV2_SWEEP(TR, DB)                                                                     \
+    hipExtLaunchKernelGGL((k_ov2_sweep<TR, DB>), grid, blk, 0, S, ev_start, sweep_done, 0, c->b,   \
+                          c->b.fcol, c->b.prow, t->ld, t->rows, c->Rp, lp, avoid, by_event ? 1 : 0, \
+                          by_event ? -1 : c->steps)
     switch (ov_tile_code(tr)) {
         case 0x04: LPR_OV2_SWEEP(4, false); break;
         case 0x10: LPR_OV2_SWEEP(16, false); break;
@@ -2019,9 +2029,8 @@ int ov2_launch_step(lpr_tableau* t, int K, int tr, int lp, int flags, hipEvent_t
         default: LPR_OV2_SWEEP(8, false); break;
     }
 #undef LPR_OV2_SWEEP
-    if (ev_stop) LPR_HIP(hipEventRecord(ev_stop, S));  // this step's sweep done
+    c->last_sweep = sweep_done;
     c->steps += 1;
-    if (by_event) LPR_HIP(hipEventRecord(c->ev_s[cur], S));
     c->ev_idx = prev;
     return LPR_OK_OPTIMAL;
 }
