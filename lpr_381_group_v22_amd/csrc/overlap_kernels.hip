@@ -35,7 +35,7 @@
 // the sweep apart (1: no multiply-subtract chains, 2: no pivot-row loads, 4: half the chains,
 // 8: plain instead of non-temporal loads / stores, 16: static grid with every XCD on a contiguous
 // range of tiles, 32: tiles taken column-major, 64 / 128: write-through stores of system / agent
-// scope).  The library is built with neither.
+// scope, 256: no half tiles at the tail of the queue).  The library is built with neither.
 #ifndef LPR_OV_DIAG
 #define LPR_OV_DIAG 0
 #endif
@@ -1441,15 +1441,18 @@ __device__ __forceinline__ void ov_rows_store(const ov_v2d (&x)[TR], ov_v2d* dst
 // launch's heads have said where they are (B.hx) -- the heads then run as fast as with nothing
 // beside them.  Wrong or missing hints cost time, never correctness: any workgroup may take any
 // tile.  `static_tile` >= 0: one given tile (the one-launch form k_ov_step has no queue).
+// TROWS rows are processed; the row tiles are counted in units of `unit` rows (>= TROWS) and this
+// call takes the TROWS rows at offset `off` inside its unit (the half tiles of the sweep's tail)
 template <int TR, bool DB, bool INPLACE, int TROWS = kOvTileRows>
 __device__ __forceinline__ void ov_one_tile(const OvBuffers& B, const OvCtl* ci,
                                             const double* __restrict__ fc,
                                             const ov_v2d* __restrict__ prow2, int tb, int ld,
-                                            int R, int Rp, int K, int cur) {
+                                            int R, int Rp, int K, int cur, int unit = TROWS,
+                                            int off = 0) {
     typedef ov_v2d v2d;
     const int ld2 = ld >> 1;
     const int nct = (ld2 + kOvNT - 1) / kOvNT;
-    const int nrt = (R + TROWS - 1) / TROWS;
+    const int nrt = (R + unit - 1) / unit;
     if (LPR_OV_DIAG & 16) {  // workgroup b sits on XCD b % 8: give each XCD consecutive tiles
         const int per = (nct * nrt + 7) / 8;
         tb = (tb % 8) * per + tb / 8;
@@ -1478,16 +1481,17 @@ __device__ __forceinline__ void ov_one_tile(const OvBuffers& B, const OvCtl* ci,
         if (LPR_OV_DIAG & 2) p[s] = v2d{(double)c2, (double)s};
         else p[s] = prow2[(size_t)s * ld2 + c2];
     }
-    const int ibase = rt * TROWS;
+    const int ibase = rt * unit + off;
     const int iend = min(R, ibase + TROWS);
+    if (ibase >= R) return;
 
     if (K == kOvMax && iend - ibase == TROWS) {
         // rows of this tile that are pivot rows of the block, as a bit mask (wave-uniform)
-        unsigned prmask = 0u;
+        unsigned long long prmask = 0ull;  // (64 bits: tiles of up to 64 rows)
 #pragma unroll
         for (int s = 0; s < kOvMax; ++s) {
             const int r = ci->r[s];
-            if (r >= ibase && r < iend) prmask |= 1u << (r - ibase);
+            if (r >= ibase && r < iend) prmask |= 1ull << (r - ibase);
         }
         const v2d* src = Tin2 + (size_t)ibase * ld2 + c2;
         v2d* dst = Tout2 + (size_t)ibase * ld2 + c2;
@@ -1499,10 +1503,10 @@ __device__ __forceinline__ void ov_one_tile(const OvBuffers& B, const OvCtl* ci,
             for (int j = 0; j < TROWS; j += 2 * TR) {
                 ov_rows_load<TR, INPLACE>(xb, src + step, ld2);
                 ov_chunk<TR>(xa, p, fc + ibase + j, Rp);
-                ov_rows_store<TR, INPLACE>(xa, dst, ld2, prmask >> j);
+                ov_rows_store<TR, INPLACE>(xa, dst, ld2, (unsigned)(prmask >> j));
                 if (j + 2 * TR < TROWS) ov_rows_load<TR, INPLACE>(xa, src + 2 * step, ld2);
                 ov_chunk<TR>(xb, p, fc + ibase + j + TR, Rp);
-                ov_rows_store<TR, INPLACE>(xb, dst + step, ld2, prmask >> (j + TR));
+                ov_rows_store<TR, INPLACE>(xb, dst + step, ld2, (unsigned)(prmask >> (j + TR)));
                 src += 2 * step;
                 dst += 2 * step;
             }
@@ -1512,7 +1516,7 @@ __device__ __forceinline__ void ov_one_tile(const OvBuffers& B, const OvCtl* ci,
                 v2d x[TR];
                 ov_rows_load<TR, INPLACE>(x, src, ld2);
                 ov_chunk<TR>(x, p, fc + ibase + j, Rp);
-                ov_rows_store<TR, INPLACE>(x, dst, ld2, prmask >> j);
+                ov_rows_store<TR, INPLACE>(x, dst, ld2, (unsigned)(prmask >> j));
                 src += step;
                 dst += step;
             }
@@ -1589,7 +1593,7 @@ __device__ __forceinline__ void ov_tiles(const OvBuffers& B, const double* __res
                                          const double* __restrict__ prow, int ld, int R, int Rp,
                                          int G, int lp, int static_tile, int avoid,
                                          bool write_ctl = true, int sweeps_done = -1) {
-    static_assert(TROWS % TR == 0 && (!DB || TROWS % (2 * TR) == 0) && TROWS <= 32,
+    static_assert(TROWS % TR == 0 && (!DB || TROWS % (2 * TR) == 0) && TROWS <= 64,
                   "tile rows: a multiple of the chunks in flight, and one bit each in prmask");
     __shared__ int s_tile;
     const OvCtl* ci = B.ctl + lp;
@@ -1633,6 +1637,12 @@ __device__ __forceinline__ void ov_tiles(const OvBuffers& B, const double* __res
     }
     const int ld2 = ld >> 1;
     const int ntiles = ((ld2 + kOvNT - 1) / kOvNT) * ((R + TROWS - 1) / TROWS);
+    // The workgroups finish their last tiles at different times and the chip drains: the last
+    // quarter of the queue is handed out as HALF tiles (a pivot-row slice load per 16 rows instead
+    // of 32 there, a shorter tail: 64-row tiles everywhere measured 181 us, 32-row 174, 16-row 172).
+    constexpr bool kHalfTail = (TROWS / 2) % TR == 0 && TROWS == kOvTileRows && (LPR_OV_DIAG & 256) == 0;
+    const int tsplit = kHalfTail ? (ntiles - ntiles / 4) : ntiles;
+    const int qtiles = tsplit + 2 * (ntiles - tsplit);
     // do loop heads that stage a block run beside this launch, and where?
     const bool heads_beside = !INPLACE && avoid > 0 && ci->status == kRunning &&
                               ci->pending == kRunning;
@@ -1646,7 +1656,7 @@ __device__ __forceinline__ void ov_tiles(const OvBuffers& B, const double* __res
                 const unsigned long long v =
                     __hip_atomic_load(B.hx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((unsigned)(v >> 32) == xepoch && ((unsigned)v & 0x1ffu) == (0x100u | my_xcc))
-                    tile = ntiles;  // this launch's heads share this XCD: leave it to them
+                    tile = qtiles;  // this launch's heads share this XCD: leave it to them
             }
             if (tile < 0)
                 tile = (int)__hip_atomic_fetch_add(B.tileq + lp, 1u, __ATOMIC_RELAXED,
@@ -1656,8 +1666,14 @@ __device__ __forceinline__ void ov_tiles(const OvBuffers& B, const double* __res
         __syncthreads();
         const int tile = s_tile;
         __syncthreads();
-        if (tile >= ntiles) return;
-        ov_one_tile<TR, DB, INPLACE, TROWS>(B, ci, fc, prow2, tile, ld, R, Rp, K, cur);
+        if (tile >= qtiles) return;
+        if (tile < tsplit) {
+            ov_one_tile<TR, DB, INPLACE, TROWS>(B, ci, fc, prow2, tile, ld, R, Rp, K, cur);
+        } else {  // the tail of the queue: half tiles
+            const int u = tile - tsplit;
+            ov_one_tile<TR, false, INPLACE, TROWS / 2>(B, ci, fc, prow2, tsplit + (u >> 1), ld, R, Rp,
+                                                       K, cur, TROWS, (u & 1) * (TROWS / 2));
+        }
     }
 }
 
