@@ -1641,7 +1641,10 @@ __device__ __forceinline__ void ov_tiles(const OvBuffers& B, const double* __res
     // quarter of the queue is handed out as HALF tiles (a pivot-row slice load per 16 rows instead
     // of 32 there, a shorter tail: 64-row tiles everywhere measured 181 us, 32-row 174, 16-row 172).
     constexpr bool kHalfTail = (TROWS / 2) % TR == 0 && TROWS == kOvTileRows && (LPR_OV_DIAG & 256) == 0;
-    const int tsplit = kHalfTail ? (ntiles - ntiles / 4) : ntiles;
+#ifndef LPR_OV_TAIL_DIV
+#define LPR_OV_TAIL_DIV 4
+#endif
+    const int tsplit = kHalfTail ? (ntiles - ntiles / LPR_OV_TAIL_DIV) : ntiles;
     const int qtiles = tsplit + 2 * (ntiles - tsplit);
     // do loop heads that stage a block run beside this launch, and where?
     const bool heads_beside = !INPLACE && avoid > 0 && ci->status == kRunning &&
