@@ -562,8 +562,9 @@ def main() -> int:
                     help="pivots of the CPU baseline sample (-1: sized for ~15 s, 0: skip)")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="replay captured graphs instead of eager launches with HIP events")
-    ap.add_argument("--time-stride", type=int, default=2,
-                    help="K-pivot paths: bracket every n-th sweep launch with HIP events (1: all)")
+    ap.add_argument("--time-stride", type=int, default=0,
+                    help="K-pivot paths: bracket every n-th sweep launch with HIP events (1: all; "
+                         "0 = auto: every launch when steps <= 32, one in two above)")
     ap.add_argument("--bb-vars", type=int, default=512)
     ap.add_argument("--bb-cons", type=int, default=64)
     ap.add_argument("--bb-levels", type=int, default=9)
@@ -572,6 +573,8 @@ def main() -> int:
         args.steps = 64 if args.workload == "primal" else 512
     if args.warmup is None:
         args.warmup = 8 if args.workload == "primal" else 64
+    if args.time_stride <= 0:
+        args.time_stride = 1 if args.steps <= 32 else 2
     D = Dist(args)
     out = {"primal": run_primal, "revised": run_revised, "bb": run_bb,
            "sens": run_sens}[args.workload](args, D)
