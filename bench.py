@@ -34,6 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+OVERLAP_BYTES = 80 << 20    # kOverlapBytes of csrc/lpr_engine.hip: above it the two-stream path runs
 MFMA_F64_PEAK_TFLOPS = 78.6  # MI355X datasheet fp64 matrix (= fp64 vector) peak; the local guide
 #                              has no fp64 MFMA row, tools/mfma_f64_peak.hip probes it on the device
 
@@ -87,9 +88,6 @@ class Dist:
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         if self.world != args.gpus:
-            if self.world == 1 and args.gpus > 1:
-                raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one "
-                                 "rank per GPU)")
             raise SystemExit(f"WORLD_SIZE={self.world} does not match --gpus {args.gpus}")
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
@@ -188,7 +186,7 @@ def run_primal(args, D: Dist):
     out = None
     if D.rank == 0:
         value = D.world * K * B / dt_max
-        two_stream = B > 1 and (args.variant & 0xff00) in (0, 0x3000) and R * C * 8 > (300 << 20)
+        two_stream = B > 1 and (args.variant & 0xff00) in (0, 0x3000) and R * C * 8 > OVERLAP_BYTES
         if B == 1 and not timed and R * C * 8 <= (1 << 20):
             kname = ("k_pivot_fused (selection + rank-1 update in one launch; the tableau is "
                      "cache-resident: effective GB/s, not an HBM fraction)")
@@ -446,6 +444,23 @@ def run_bb(args, D: Dist):
                              f"the same root, first {ref['processed']} nodes popped ({cpiv} "
                              f"sub-problem pivots), C oracle, 1 thread; cpu: {_cpu_model()}",
                    "nodes_per_s": round(ref["processed"] / cdt, 2)}
+            # the same level-synchronous search on the oracle for the first `chk` levels, against
+            # a fresh tree on the device: node / pivot counts, incumbent bits, status
+            from oracle_evaluator import OracleEvaluator
+            chk = min(levels, args.bb_check_levels)
+            if chk > 0:
+                oref = pkg.solve_level_synchronous(OracleEvaluator(orc, T, nv), nv, max_levels=chk)
+                tchk = pkg.BranchBoundTree.from_tableau(primal.tableau, nv, max_depth=chk + 2)
+                gchk = pkg.solve_level_sync_native(tchk, max_levels=chk)
+                tchk.destroy()
+                same = all(gchk[k] == oref[k] for k in ("processed", "pivots", "levels", "found",
+                                                        "status"))
+                same = same and (np.float64(gchk["z"]).tobytes() == np.float64(oref["z"]).tobytes())
+                if oref["found"]:
+                    same = same and np.array(gchk["x"]).tobytes() == np.array(oref["x"]).tobytes()
+                cpu["matches_oracle"] = bool(same)
+                cpu["matches_oracle_over"] = (f"{chk} levels, {oref['processed']} nodes, "
+                                              f"{oref['pivots']} pivots")
         out = {
             "metric": "Branch&Bound sub-problem pivots/sec (level-synchronous, sub-trees sharded)",
             "value": round(res["pivots"] / dt_max, 2), "unit": "pivots/s", "n_gpus": D.world,
@@ -547,6 +562,35 @@ def run_sens(args, D: Dist):
     return out
 
 
+def _self_launch(n: int) -> int:
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks as FRESH
+    child processes (python -m torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1)
+    BEFORE this process has touched the GPU -- it never does -- and relay rank 0's JSON line.  A
+    process that has initialised the GPU is never re-executed."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__), *sys.argv[1:]]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    for ln in proc.stdout.splitlines():
+        if not ln.startswith("{"):
+            sys.stderr.write(ln + "\n")
+    if proc.returncode != 0 or not lines:
+        sys.stderr.write(f"bench.py: the {n}-rank launch ended with code {proc.returncode} and "
+                         f"{len(lines)} result line(s)\n")
+        return proc.returncode or 1
+    print(lines[-1], flush=True)
+    return 0
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -568,6 +612,8 @@ def main() -> int:
     ap.add_argument("--bb-vars", type=int, default=512)
     ap.add_argument("--bb-cons", type=int, default=64)
     ap.add_argument("--bb-levels", type=int, default=9)
+    ap.add_argument("--bb-check-levels", type=int, default=6,
+                    help="levels of the same search repeated on the CPU oracle and compared")
     args = ap.parse_args()
     if args.steps is None:
         args.steps = 64 if args.workload == "primal" else 512
@@ -575,6 +621,8 @@ def main() -> int:
         args.warmup = 8 if args.workload == "primal" else 64
     if args.time_stride <= 0:
         args.time_stride = 1 if args.steps <= 32 else 2
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return _self_launch(args.gpus)
     D = Dist(args)
     out = {"primal": run_primal, "revised": run_revised, "bb": run_bb,
            "sens": run_sens}[args.workload](args, D)

@@ -44,6 +44,8 @@ extern "C" {
  *   PIVOT_LIMIT          (no reference equivalent: the C# loops are uncapped; returned only when
  *                         the caller sets max_pivots)
  *   BB_NODE_CAP          BranchBoundSimplexSolver.cs:1038-1042 ("Potential infinite loop detected")
+ *   BB_DEPTH_CAP         (no reference equivalent: lpr_bb_solve_level_sync stopped at max_levels
+ *                         with fractional nodes it scored but did not branch)
  */
 typedef enum lpr_status {
     LPR_OK_OPTIMAL = 0,
@@ -53,6 +55,7 @@ typedef enum lpr_status {
     LPR_ENTERING_ALREADY_BASIC = 4,
     LPR_PIVOT_LIMIT = 5,
     LPR_BB_NODE_CAP = 6,
+    LPR_BB_DEPTH_CAP = 7,
     LPR_BAD_ARGUMENT = -1,
     LPR_DEVICE_ERROR = -2,
     LPR_OUT_OF_MEMORY = -3
@@ -396,11 +399,14 @@ typedef struct lpr_bb_sync_opts {
 } lpr_bb_sync_opts;
 
 typedef struct lpr_bb_sync_result {
-    int32_t status;      /* LPR_OK_OPTIMAL, or LPR_BB_NODE_CAP when max_nodes stopped it */
+    int32_t status;      /* LPR_OK_OPTIMAL; LPR_BB_NODE_CAP when max_nodes stopped it; LPR_BB_DEPTH_CAP
+                          * when max_levels did (the nodes of that depth are still scored); < 0: a
+                          * rank failed and EVERY rank returns that status from the same level */
     int32_t found;       /* 0: no integer solution */
     int64_t processed;   /* nodes scored, all ranks */
     int64_t pivots;      /* dual + primal pivots of all child LPs, all ranks */
-    int32_t levels;      /* levels done = all-reduces issued */
+    int32_t levels;      /* levels branched (depth reached).  All-reduces issued = levels, + 1 when a
+                          * scoring-only pass over the depth-max_levels frontier followed */
     int32_t path_len;    /* the winner's branch path: path_len sides from the root ... */
     uint64_t path_bits;  /* ... bit k = side taken at depth k (0 lower "<= floor", 1 upper) */
     double z;            /* incumbent objective (rounded to 4 decimals like every B&B value) */
@@ -410,10 +416,17 @@ typedef struct lpr_bb_sync_result {
  * frontier (IsInteger :595-599, CheckIntegerBasicVar :829-847), branches (CreateBranches
  * :859-890), evaluates ALL children in one batch (AddConstraint + DoDualSimplex on the device)
  * and issues ONE all-reduce(MAX) of {incumbent z, "someone has nodes left", "someone hit
- * max_nodes"}.  The first ceil(log2(world)) levels are done by every rank alike; the frontier at
+ * max_nodes", "someone failed" (its lpr_status), "someone left nodes unbranched at max_levels"}.
+ * A rank-local failure (device error, out of memory, a cycling child's pivot limit) is never
+ * returned before that collective: it rides in it, so all ranks return it together instead of the
+ * healthy ones waiting for ever (the per-branch catch of :1145-1148,1205-1208 is the reference's
+ * analogue).  Every rank must pass the same opts and handles of the same max_depth.  The first ceil(log2(world)) levels are done by every rank alike; the frontier at
  * that depth is dealt round robin in DFS order and a sub-tree then stays on its rank -- tableaux
- * never move.  Ties on z go to the node the reference's stack pops first.  One all-gather at the
- * end names the winner.  comm == NULL: a single rank.  Every rank passes a handle holding the
+ * never move.  With pruning off (the reference's setting, Program.cs:389) ties on z go to the node
+ * the reference's stack pops first; with enable_pruning a tied integer node that the DFS would
+ * have met BEFORE the incumbent may be pruned here (same z, possibly another x).  One all-gather
+ * at the end names the winner.  Test hook: the environment variable LPR_BB_INJECT_FAULT=
+ * "<rank>:<level>" makes that rank fail at that level.  comm == NULL: a single rank.  Every rank passes a handle holding the
  * same root; x (nvars) is written on every rank when found. */
 int lpr_bb_solve_level_sync(lpr_bb* b, lpr_comm* comm, const lpr_bb_sync_opts* opts, double* x,
                             lpr_bb_sync_result* res);

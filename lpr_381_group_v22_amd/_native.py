@@ -20,13 +20,14 @@ LPR_PIVOT_TOO_SMALL = 3
 LPR_ENTERING_ALREADY_BASIC = 4
 LPR_PIVOT_LIMIT = 5
 LPR_BB_NODE_CAP = 6
+LPR_BB_DEPTH_CAP = 7
 LPR_BAD_ARGUMENT = -1
 LPR_DEVICE_ERROR = -2
 LPR_OUT_OF_MEMORY = -3
 
 STATUS_NAMES = {
     0: "OPTIMAL", 1: "UNBOUNDED", 2: "INFEASIBLE_BASIS", 3: "PIVOT_TOO_SMALL",
-    4: "ENTERING_ALREADY_BASIC", 5: "PIVOT_LIMIT", 6: "BB_NODE_CAP",
+    4: "ENTERING_ALREADY_BASIC", 5: "PIVOT_LIMIT", 6: "BB_NODE_CAP", 7: "BB_DEPTH_CAP",
     -1: "BAD_ARGUMENT", -2: "DEVICE_ERROR", -3: "OUT_OF_MEMORY",
 }
 

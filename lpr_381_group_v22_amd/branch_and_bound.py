@@ -254,17 +254,20 @@ def solve_level_synchronous(evaluator, nvars: int, *, rank: int = 0, world: int 
     root -- sub-problems are independent LPs, nothing but the incumbent crosses xGMI.
 
     Per level: each rank scores its frontier nodes, updates its local incumbent, branches, and
-    evaluates all its children in ONE batched ``expand``; then ONE ``all_reduce(MAX)`` of three
-    doubles: the incumbent objective, "some rank still has nodes", "some rank passed max_nodes" --
-    so every rank leaves the loop on the same level.  ``all_reduce_max`` takes and returns a list.
+    evaluates all its children in ONE batched ``expand``; then ONE ``all_reduce(MAX)`` of five
+    doubles: the incumbent objective, "some rank still has nodes", "some rank passed max_nodes",
+    "some rank failed", "some rank left nodes unbranched at max_levels" -- so every rank leaves the
+    loop on the same level, also when one of them raised (the exception is re-raised on that rank
+    and a RuntimeError on the others AFTER the collective; nobody hangs).  The frontier of depth
+    max_levels is scored, not branched (status LPR_BB_DEPTH_CAP if a fractional node was left).  ``all_reduce_max`` takes and returns a list.
     (This is the Python mirror of ``lpr_bb_solve_level_sync`` -- the C ABI form, which calls RCCL
     itself -- kept for the CPU tests with a stand-in evaluator.)  With
     pruning off (the reference's setting, Program.cs:389) the explored tree does not depend on the
     rank count, and ties on z go to the node the reference's stack pops first (lower child before
     upper child, parent before child), so the answer equals ExecuteBranchAndBound without its
-    20-node cap.  Returns dict(x, z, found, processed, pivots, levels, path), same on all ranks."""
+    20-node cap.  Returns dict(x, z, found, processed, pivots, levels, path, status), same on all ranks."""
     if all_reduce_max is None:
-        all_reduce_max = lambda v: list(v)  # noqa: E731  (takes and returns a 3-list)
+        all_reduce_max = lambda v: list(v)  # noqa: E731  (takes and returns a 5-list)
     if gather is None:
         gather = lambda obj: [obj]  # noqa: E731
     split_level = 0
@@ -279,47 +282,61 @@ def solve_level_synchronous(evaluator, nvars: int, *, rank: int = 0, world: int 
     processed = 0
     pivots = 0
     levels = 0
-    while levels < max_levels:
+    capped = depth_capped = False
+    failure = None  # (rank-local exception, or the fact that a peer failed)
+    while True:
+        # a level past max_levels is scored but not branched (lpr_bb_solve_level_sync does the same)
+        may_expand = levels < max_levels
         replicated = levels < split_level  # every rank is doing the same nodes
         count_here = (not replicated) or rank == 0
         parents, var, bound, kind, paths = [], [], [], [], []
-        if frontier:
-            ids = [nid for nid, _ in frontier]
-            zs, vals = evaluator.node_info(ids)
-            all_int, bvar, bval = score_nodes(vals)
-            for q, ((nid, path), z) in enumerate(zip(frontier, zs)):
-                if count_here:
-                    processed += 1
-                if enable_pruning and global_bound > -math.inf and z <= global_bound:
-                    continue  # ShouldPrunebranch :995-1001 against the all-reduced bound
-                if all_int[q]:  # UpdateOptimalSolution :943-981
-                    cand = (float(z), path, [float(t) for t in vals[q]])
-                    if best_local is None or cand[0] > best_local[0] or \
-                            (cand[0] == best_local[0] and _dfs_before(cand[1], best_local[1])):
-                        best_local = cand
-                        best_z = max(best_z, cand[0])
-                k = int(bvar[q])  # CreateBranches :859-890
-                if k < 0:
-                    continue
-                val = float(bval[q])
-                for side, bnd in ((0, math.floor(val)), (1, math.ceil(val))):
-                    parents.append(nid)
-                    var.append(k)
-                    bound.append(float(int(bnd)))
-                    kind.append(side)
-                    paths.append(path + (side,))
         new_frontier: List[Tuple[int, Tuple[int, ...]]] = []
-        if parents:
-            child, st, piv = evaluator.expand(parents, var, bound, kind)
-            if count_here:
-                pivots += int(np.sum(piv))
-            for c, s2, pth in zip(child, st, paths):
-                if s2 == BB_SOLVED:
-                    new_frontier.append((int(c), pth))
+        local_err = None  # never raised before the collective: the peers would wait for ever
+        unbranched = False
+        try:
+            if frontier:
+                ids = [nid for nid, _ in frontier]
+                zs, vals = evaluator.node_info(ids)
+                all_int, bvar, bval = score_nodes(vals)
+                for q, ((nid, path), z) in enumerate(zip(frontier, zs)):
+                    if count_here:
+                        processed += 1
+                    if enable_pruning and global_bound > -math.inf and z <= global_bound:
+                        continue  # ShouldPrunebranch :995-1001 against the all-reduced bound
+                    if all_int[q]:  # UpdateOptimalSolution :943-981
+                        cand = (float(z), path, [float(t) for t in vals[q]])
+                        if best_local is None or cand[0] > best_local[0] or \
+                                (cand[0] == best_local[0] and _dfs_before(cand[1], best_local[1])):
+                            best_local = cand
+                            best_z = max(best_z, cand[0])
+                    k = int(bvar[q])  # CreateBranches :859-890
+                    if k < 0:
+                        continue
+                    if not may_expand:
+                        unbranched = True
+                        continue
+                    val = float(bval[q])
+                    for side, bnd in ((0, math.floor(val)), (1, math.ceil(val))):
+                        parents.append(nid)
+                        var.append(k)
+                        bound.append(float(int(bnd)))
+                        kind.append(side)
+                        paths.append(path + (side,))
+            if parents:
+                child, st, piv = evaluator.expand(parents, var, bound, kind)
+                if count_here:
+                    pivots += int(np.sum(piv))
+                for c, s2, pth in zip(child, st, paths):
+                    if s2 == BB_SOLVED:
+                        new_frontier.append((int(c), pth))
+        except Exception as exc:  # noqa: BLE001 -- carried through the all-reduce below
+            local_err = exc
+            new_frontier = []
         if frontier:
             evaluator.release([nid for nid, _ in frontier])
-        levels += 1
-        if levels == split_level and world > 1:
+        if may_expand:
+            levels += 1
+        if may_expand and levels == split_level and world > 1 and local_err is None:
             # deal the depth-L0 frontier: identical on every rank, so no communication is needed
             new_frontier.sort(key=lambda e: e[1])
             keep = [e for i, e in enumerate(new_frontier) if i % world == rank]
@@ -328,28 +345,41 @@ def solve_level_synchronous(evaluator, nvars: int, *, rank: int = 0, world: int 
                 evaluator.release(drop)
             new_frontier = keep
         frontier = new_frontier
-        # ---- the single collective of the level (RCCL all-reduce over xGMI): the incumbent
-        # bound; "someone still has nodes" rides in the same MAX as a large offset-free flag ----
+        # ---- the single collective of the level (RCCL all-reduce over xGMI): the incumbent bound,
+        # "someone still has nodes", "someone passed max_nodes", "someone FAILED", "someone left
+        # nodes unbranched at max_levels" ride in the same MAX ----
         red = all_reduce_max([best_z, 1.0 if frontier else 0.0,
-                              1.0 if processed > max_nodes else 0.0])
-        global_bound, busy, capped = float(red[0]), red[1] > 0.5, red[2] > 0.5
-        if not busy or capped:  # decided from the same reduced values on every rank
+                              1.0 if processed > max_nodes else 0.0,
+                              1.0 if local_err is not None else 0.0,
+                              1.0 if unbranched else 0.0])
+        global_bound, busy = float(red[0]), red[1] > 0.5
+        capped = capped or red[2] > 0.5
+        depth_capped = depth_capped or red[4] > 0.5
+        if red[3] > 0.5:  # every rank leaves on this level, with an error
+            failure = local_err if local_err is not None else RuntimeError(
+                f"solve_level_synchronous: another rank failed at level {levels} "
+                f"(this rank, {rank} of {world}, was fine)")
+            break
+        if not busy or capped or not may_expand:  # decided from the same reduced values everywhere
             break
     if frontier:
         evaluator.release([nid for nid, _ in frontier])
+    if failure is not None:
+        raise failure
+    status = N.LPR_BB_NODE_CAP if capped else (N.LPR_BB_DEPTH_CAP if depth_capped else 0)
     # winner identity: one gather at termination, ties by DFS order (:966 "first found wins")
     cands = [c for c in gather(best_local) if c is not None]
     total_processed = int(sum(gather(processed)))
     total_pivots = int(sum(gather(pivots)))
     if not cands:
         return dict(x=None, z=-math.inf, found=False, processed=total_processed,
-                    pivots=total_pivots, levels=levels, path=None)
+                    pivots=total_pivots, levels=levels, path=None, status=status)
     best = cands[0]
     for c in cands[1:]:
         if c[0] > best[0] or (c[0] == best[0] and _dfs_before(c[1], best[1])):
             best = c
     return dict(x=best[2], z=best[0], found=True, processed=total_processed,
-                pivots=total_pivots, levels=levels, path=best[1])
+                pivots=total_pivots, levels=levels, path=best[1], status=status)
 
 
 def _dfs_before(a: Tuple[int, ...], b: Tuple[int, ...]) -> bool:

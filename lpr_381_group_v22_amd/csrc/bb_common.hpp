@@ -6,6 +6,10 @@
 
 namespace lpr {
 
+// k_bb_eliminate keeps one int per column of a child in dynamic LDS (above its 8 KB of static LDS):
+// 144 KB of the CU's 160 KB = 36 864 columns.  lpr_bb_create rejects wider trees.
+constexpr size_t kBBEliminateLdsMax = (size_t)144 << 10;
+
 // States of one child LP while DoDualSimplex (:289-468) runs on it.
 enum : int32_t {
     kBBDual = 0,        // dual phase (:305-343)

@@ -357,6 +357,12 @@ static int bb_create_common(lpr_engine* e, int rows, int cols, int nvars, int ma
         set_error("lpr_bb_create: rows + max_depth exceeds 65535");
         return LPR_BAD_ARGUMENT;
     }
+    if ((size_t)align_up(cols + max_depth, kLdAlign) * sizeof(int) > kBBEliminateLdsMax) {
+        // k_bb_eliminate (AddConstraint :756-796) ranks the basic columns of a child in LDS
+        set_error("lpr_bb_create: cols + max_depth = %d exceeds the %zu columns the Branch & Bound "
+                  "kernels keep in LDS", cols + max_depth, kBBEliminateLdsMax / sizeof(int));
+        return LPR_BAD_ARGUMENT;
+    }
     LPR_HIP(hipSetDevice(e->device));
     lpr_bb* b = new (std::nothrow) lpr_bb();
     if (!b) return LPR_OUT_OF_MEMORY;
@@ -677,6 +683,10 @@ struct Front {
     int node;
     Path path;
 };
+// A rank-local lpr_status as a slot of the level's MAX all-reduce: 0 = fine, failures (< 0) above
+// the non-fatal stops (> 0) so that the worst one wins.
+double bb_encode_rc(int rc) { return rc == 0 ? 0.0 : (rc < 0 ? 1000.0 - (double)rc : (double)rc); }
+int bb_decode_rc(double e) { return e > 1000.0 ? -(int)(e - 1000.0) : (int)e; }
 
 }  // namespace
 
@@ -726,9 +736,23 @@ int lpr_bb_solve_level_sync(lpr_bb* b, lpr_comm* comm, const lpr_bb_sync_opts* o
     std::vector<double> zs, vals, bound;
     std::vector<Path> paths;
 
-    while (levels < max_levels) {
+    // Test hook (fault injection, tests/test_bb_gpu.py): LPR_BB_INJECT_FAULT="<rank>:<level>" makes
+    // that rank's batch of that level fail as a device error would.
+    int fault_rank = -1, fault_level = -1;
+    if (const char* fv = std::getenv("LPR_BB_INJECT_FAULT"))
+        if (std::sscanf(fv, "%d:%d", &fault_rank, &fault_level) != 2) fault_rank = fault_level = -1;
+
+    int agreed_rc = LPR_OK_OPTIMAL;  // a failure of ANY rank, learnt by all from the level's all-reduce
+    bool depth_capped = false;
+    for (;;) {
+        // A level past max_levels is scored but not branched: its nodes were solved by the level
+        // before and would otherwise be dropped unseen (an integer optimum sitting exactly at depth
+        // max_levels).  Nodes left unbranched there make the result LPR_BB_DEPTH_CAP.
+        const bool may_expand = levels < max_levels;
         const bool replicated = levels < split_level;  // every rank is doing the same nodes
         const bool count_here = !replicated || rank == 0;
+        int local_rc = LPR_OK_OPTIMAL;  // never returned before the collective: the peers would hang
+        bool unbranched = false;
         parents.clear(); var.clear(); bound.clear(); kind.clear(); paths.clear();
         if (!frontier.empty()) {
             const int cnt = (int)frontier.size();
@@ -737,10 +761,9 @@ int lpr_bb_solve_level_sync(lpr_bb* b, lpr_comm* comm, const lpr_bb_sync_opts* o
             zs.assign(cnt, 0.0);
             vals.assign((size_t)cnt * (n > 0 ? n : 1), 0.0);
             const double t_i = bb_now();
-            int rc = bb_node_info(b, ids.data(), cnt, zs.data(), vals.data());
+            local_rc = bb_node_info(b, ids.data(), cnt, zs.data(), vals.data());
             b->prof.info += bb_now() - t_i;
-            if (rc != LPR_OK_OPTIMAL) return rc;
-            for (int q = 0; q < cnt; ++q) {
+            for (int q = 0; q < cnt && local_rc == LPR_OK_OPTIMAL; ++q) {
                 const double* v = vals.data() + (size_t)q * n;
                 const double z = zs[q];
                 if (count_here) ++processed;
@@ -769,6 +792,7 @@ int lpr_bb_solve_level_sync(lpr_bb* b, lpr_comm* comm, const lpr_bb_sync_opts* o
                     }
                 }
                 if (bestVar < 0) continue;  // an integer node has no children (:1070-1076)
+                if (!may_expand) { unbranched = true; continue; }
                 for (int side = 0; side < 2; ++side) {  // CreateBranches :859-890
                     parents.push_back(frontier[q].node);
                     var.push_back(bestVar);
@@ -783,24 +807,28 @@ int lpr_bb_solve_level_sync(lpr_bb* b, lpr_comm* comm, const lpr_bb_sync_opts* o
             }
         }
         std::vector<Front> next;
-        if (!parents.empty()) {
+        if (local_rc == LPR_OK_OPTIMAL && !parents.empty()) {
             const int cnt = (int)parents.size();
             child.assign(cnt, -1);
             cst.assign(cnt, 0);
             cpiv.assign(cnt, 0);
             const double t_e = bb_now();
-            int rc = bb_expand(b, cnt, parents.data(), var.data(), bound.data(), kind.data(),
-                               child.data(), cst.data(), cpiv.data(), nullptr, nullptr);
+            local_rc = bb_expand(b, cnt, parents.data(), var.data(), bound.data(), kind.data(),
+                                 child.data(), cst.data(), cpiv.data(), nullptr, nullptr);
             b->prof.expand += bb_now() - t_e;
-            if (rc != LPR_OK_OPTIMAL) return rc;
-            for (int q = 0; q < cnt; ++q) {
+            for (int q = 0; q < cnt && local_rc == LPR_OK_OPTIMAL; ++q) {
                 if (count_here) pivots += cpiv[q];
                 if (cst[q] == kBBSolved) next.push_back({child[q], paths[q]});
             }
         }
+        if (rank == fault_rank && levels == fault_level && local_rc == LPR_OK_OPTIMAL) {
+            set_error("lpr_bb_solve_level_sync: injected fault (LPR_BB_INJECT_FAULT) on rank %d, "
+                      "level %d", rank, levels);
+            local_rc = LPR_DEVICE_ERROR;
+        }
         for (const Front& f : frontier) bb_release_node(b, f.node);
-        ++levels;
-        if (levels == split_level && world > 1) {
+        if (may_expand) ++levels;
+        if (may_expand && levels == split_level && world > 1 && local_rc == LPR_OK_OPTIMAL) {
             // deal the frontier of this depth: identical on every rank, so nothing is exchanged
             std::stable_sort(next.begin(), next.end(),
                              [](const Front& a, const Front& c) { return dfs_before(a.path, c.path); });
@@ -813,18 +841,43 @@ int lpr_bb_solve_level_sync(lpr_bb* b, lpr_comm* comm, const lpr_bb_sync_opts* o
         }
         frontier.swap(next);
         // ---- the single collective of the level: incumbent bound, "someone has nodes left",
-        //      "someone has hit max_nodes" -- all three decided by every rank from the same sums
-        double red[3] = {best_z_local, frontier.empty() ? 0.0 : 1.0,
-                         processed > max_nodes ? 1.0 : 0.0};
+        //      "someone has hit max_nodes", "someone FAILED" (its status, so that every rank leaves
+        //      on this level with it instead of waiting for ever in the next collective), "someone
+        //      left nodes unbranched at max_levels" -- all decided by every rank from the same maxima
+        double red[5] = {best_z_local, frontier.empty() ? 0.0 : 1.0,
+                         processed > max_nodes ? 1.0 : 0.0, bb_encode_rc(local_rc),
+                         unbranched ? 1.0 : 0.0};
         const double t_c = bb_now();
-        int rc = comm_all_reduce_max(comm, red, 3);
+        int rc = comm_all_reduce_max(comm, red, 5);
         b->prof.comm += bb_now() - t_c;
-        if (rc != LPR_OK_OPTIMAL) return rc;
+        if (rc != LPR_OK_OPTIMAL) {  // the transport itself is gone: nothing left to agree through
+            for (const Front& f : frontier) bb_release_node(b, f.node);
+            return rc;
+        }
         global_bound = red[0];
+        if (red[3] > 0.5) {
+            agreed_rc = bb_decode_rc(red[3]);
+            if (local_rc == LPR_OK_OPTIMAL)
+                set_error("lpr_bb_solve_level_sync: another rank failed with status %d at level %d "
+                          "(this rank, %d of %d, was fine)", agreed_rc, levels, rank, world);
+            break;
+        }
         if (red[2] > 0.5) capped = true;
-        if (red[1] < 0.5 || capped) break;
+        if (red[4] > 0.5) depth_capped = true;
+        if (red[1] < 0.5 || capped || !may_expand) break;
     }
     for (const Front& f : frontier) bb_release_node(b, f.node);
+    if (agreed_rc != LPR_OK_OPTIMAL) {  // every rank is here on the same level: no gather
+        res->status = agreed_rc;
+        res->found = 0;
+        res->processed = processed;
+        res->pivots = pivots;
+        res->levels = levels;
+        res->path_len = 0;
+        res->path_bits = 0;
+        res->z = -INFINITY;
+        return agreed_rc;
+    }
 
     // winner identity: one gather at termination, ties by DFS order (:966 "first found wins")
     const int nx = n > 0 ? n : 1;
@@ -869,7 +922,7 @@ int lpr_bb_solve_level_sync(lpr_bb* b, lpr_comm* comm, const lpr_bb_sync_opts* o
                      1e3 * (bb_now() - t_begin), 1e3 * b->prof.info, 1e3 * b->prof.expand,
                      1e3 * b->prof.alloc, b->prof.mallocs, 1e3 * b->prof.slots, 1e3 * b->prof.comm,
                      b->prof.polls, b->prof.steps);
-    res->status = capped ? LPR_BB_NODE_CAP : LPR_OK_OPTIMAL;
+    res->status = capped ? LPR_BB_NODE_CAP : (depth_capped ? LPR_BB_DEPTH_CAP : LPR_OK_OPTIMAL);
     res->found = found ? 1 : 0;
     res->processed = tot_proc;
     res->pivots = tot_piv;

@@ -668,7 +668,17 @@ void bb_launch_add_constraint(lpr_bb* b, int nslots, int nparents, int rows_max,
                        b->d_slots, b->ld, b->bflag, b->bkey);
     // (:799 RoundTableau and the -0 pass of :307-313 are applied by child_init / eliminate as they
     // write: no separate pass over the children)
-    hipLaunchKernelGGL(k_bb_eliminate, dim3(nslots), dim3(1024), (size_t)b->ld * sizeof(int), st,
+    const size_t elim_lds = (size_t)b->ld * sizeof(int);  // <= kBBEliminateLdsMax (lpr_bb_create)
+    if (elim_lds > (48u << 10)) {
+        static bool raised = false;  // one process = one GPU
+        if (!raised) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bb_eliminate),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)kBBEliminateLdsMax);
+            raised = true;
+        }
+    }
+    hipLaunchKernelGGL(k_bb_eliminate, dim3(nslots), dim3(1024), elim_lds, st,
                        b->d_slots, b->ld, b->bflag, b->bkey, b->blist);
 }
 

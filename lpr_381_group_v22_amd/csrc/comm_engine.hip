@@ -23,6 +23,7 @@ struct lpr_comm {
     lpr_allgather_fn ag = nullptr;
     void* user = nullptr;
     int64_t allreduce_calls = 0, allgather_calls = 0;
+    bool orphaned = false;              // its engine was closed first
 };
 
 namespace lpr {
@@ -37,6 +38,28 @@ namespace lpr {
         }                                                                                 \
     } while (0)
 
+// lpr_engine_close with the communicator still alive: RCCL's resources go with the stream they
+// were used on; the handle stays valid for lpr_comm_destroy / lpr_comm_info and refuses collectives.
+static void comm_release_device(lpr_comm* c) {
+    if (c->nccl) {
+        hipSetDevice(c->eng->device);
+        hipStreamSynchronize(c->eng->stream);
+        ncclCommDestroy(c->nccl);
+        c->nccl = nullptr;
+    }
+    hipFree(c->d_buf);
+    hipFree(c->d_send);
+    hipFree(c->d_recv);
+    c->d_buf = nullptr;
+    c->d_send = c->d_recv = nullptr;
+    c->gather_cap = 0;
+}
+void comm_orphan(lpr_comm* c) {
+    comm_release_device(c);
+    c->eng = nullptr;
+    c->orphaned = true;
+}
+
 int comm_rank(const lpr_comm* c) { return c ? c->rank : 0; }
 int comm_world(const lpr_comm* c) { return c ? c->world : 1; }
 
@@ -44,6 +67,10 @@ int comm_world(const lpr_comm* c) { return c ? c->world : 1; }
 int comm_all_reduce_max(lpr_comm* c, double* v, int n) {
     if (!c || (c->world == 1 && !c->nccl && !c->ar)) return LPR_OK_OPTIMAL;
     if (n < 1 || n > 64) return LPR_BAD_ARGUMENT;
+    if (c->orphaned) {
+        set_error("lpr_comm: the engine of this communicator has been closed");
+        return LPR_BAD_ARGUMENT;
+    }
     c->allreduce_calls += 1;
     if (c->ar) {
         if (c->ar(c->user, v, n) != 0) {
@@ -66,6 +93,10 @@ int comm_all_gather(lpr_comm* c, const void* send, void* recv, int bytes) {
     if (!c || (c->world == 1 && !c->nccl && !c->ag)) {
         std::memcpy(recv, send, (size_t)bytes);
         return LPR_OK_OPTIMAL;
+    }
+    if (c->orphaned) {
+        set_error("lpr_comm: the engine of this communicator has been closed");
+        return LPR_BAD_ARGUMENT;
     }
     c->allgather_calls += 1;
     if (c->ag) {
@@ -135,6 +166,7 @@ int lpr_comm_init(lpr_engine* e, int rank, int world, const uint8_t id[LPR_COMM_
         delete c;
         return LPR_OUT_OF_MEMORY;
     }
+    e->live_comm.push_back(c);
     *out = c;
     return LPR_OK_OPTIMAL;
 }
@@ -158,14 +190,15 @@ int lpr_comm_init_custom(int rank, int world, lpr_allreduce_max_fn all_reduce_ma
 
 int lpr_comm_destroy(lpr_comm* c) {
     if (!c) return LPR_BAD_ARGUMENT;
-    if (c->nccl) {
-        hipSetDevice(c->eng->device);
-        hipStreamSynchronize(c->eng->stream);
-        ncclCommDestroy(c->nccl);
+    if (c->eng) {
+        comm_release_device(c);
+        auto& lv = c->eng->live_comm;
+        for (size_t k = 0; k < lv.size(); ++k)
+            if (lv[k] == c) {
+                lv.erase(lv.begin() + k);
+                break;
+            }
     }
-    hipFree(c->d_buf);
-    hipFree(c->d_send);
-    hipFree(c->d_recv);
     delete c;
     return LPR_OK_OPTIMAL;
 }

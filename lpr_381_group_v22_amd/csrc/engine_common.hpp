@@ -60,6 +60,7 @@ struct lpr_tableau;
 struct lpr_revised;
 struct lpr_bb;
 struct lpr_sens;
+struct lpr_comm;
 
 struct lpr_engine {
     int device = 0;
@@ -72,6 +73,7 @@ struct lpr_engine {
     std::vector<lpr_revised*> live_rev;
     std::vector<lpr_bb*> live_bb;
     std::vector<lpr_sens*> live_sens;
+    std::vector<lpr_comm*> live_comm;  // RCCL communicators whose collectives run on this stream
 };
 
 struct lpr_tableau {

@@ -4,6 +4,8 @@
 // word per batch.  There is no CPU fallback: without a gfx950 device lpr_engine_open fails.
 #include "engine_common.hpp"
 
+#include <cstdlib>
+
 #include <cstdarg>
 #include <new>
 
@@ -72,6 +74,7 @@ void rev_orphan(lpr_revised* s);
 void bb_orphan(lpr_bb* b);
 // sens_engine.hip
 void sens_orphan(lpr_sens* s);
+void comm_orphan(lpr_comm* c);
 }  // namespace lpr
 // cut_kernels.hip
 void lpr_cut_release(lpr_tableau* t);
@@ -94,6 +97,13 @@ static int alloc_tableau(lpr_engine* e, int rows, int cols, lpr_tableau** out) {
     t->cols = cols;
     t->ld = align_up(cols, kLdAlign);
     t->log_cap = 1 << 16;
+    // Test hook: a small initial pivot-log capacity (LPR_TEST_LOG_CAP pairs, 16..65536) so that the
+    // growth path (ensure_log + the K-pivot paths' ov_set_log / blk_set_log_cap) is crossed after a
+    // few blocks, inside a solve short enough for the CPU oracle to check (tests/test_block_gpu.py).
+    if (const char* lc = std::getenv("LPR_TEST_LOG_CAP")) {
+        const long v = std::strtol(lc, nullptr, 10);
+        if (v >= 16 && v <= (1 << 16)) t->log_cap = v;
+    }
     const size_t tbytes = (size_t)rows * t->ld * sizeof(double);
     hipError_t err = hipSuccess;
     auto chk = [&](hipError_t x) { if (err == hipSuccess) err = x; };
@@ -704,6 +714,8 @@ int lpr_engine_close(lpr_engine* e) {
     e->live_bb.clear();
     for (lpr_sens* q : e->live_sens) sens_orphan(q);
     e->live_sens.clear();
+    for (lpr_comm* c : e->live_comm) comm_orphan(c);
+    e->live_comm.clear();
     if (e->stream) {
         hipStreamSynchronize(e->stream);
         hipStreamDestroy(e->stream);

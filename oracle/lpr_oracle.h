@@ -77,6 +77,13 @@ int orc_revised_solve(int n, int m, const double* objective, const double* A, co
                       double* Binv_out, double* xB_out, int32_t* log_row, int32_t* log_enter,
                       int32_t* log_leave, int64_t log_cap, int64_t* iterations);
 
+/* ONE pass of Solve()'s loop body (:89-215) from a given (B^-1, basis); see oracle_revised.c */
+int orc_revised_iterate_from(int n, int m, const double* objective, const double* A,
+                             const double* b, int is_min, double* Binv, int32_t* basis,
+                             double* xB_out, double* y_out, double* rcX_out, double* rcS_out,
+                             double* u_out, double* ratios_out, int32_t* entering,
+                             int32_t* leaving_row);
+
 /* ---- Branch & Bound (IntegerProgramming/BranchBoundSimplexSolver.cs, BranchAndBoundAdapter.cs) ---- */
 double orc_round_int(double x); /* .NET Framework Math.Round(double)     */
 double orc_round4(double x);    /* .NET Framework Math.Round(double, 4)  */
@@ -90,6 +97,10 @@ int orc_bb_solve(const double* final_tableau, int rows, int cols, int nvars, int
 /* AddConstraint :694-803 for one constraint (coefficients..., bound, type); out is (rows+1)x(cols+1) */
 int orc_bb_add_constraint(const double* base, int rows, int cols, const double* con, int conLen,
                           double* out);
+/* RoundTableau :552-567 in place; a popped node's RoundAllTableaux :1047 + GetObjective :892-897 +
+ * decision values :805-857 / :899-921 (T rounded in place) */
+void orc_bb_round_tableau(double* T, int rows, int cols);
+void orc_bb_node_info(double* T, int rows, int cols, int nvars, double* z, double* vals);
 /* DoDualSimplex :289-468 (tableauOverride mode): 0 solved, 1 infeasible, 2 exception escaped */
 int orc_bb_dual_simplex(const double* start, int rows, int cols, double* out, int* npiv,
                         int32_t* piv_trace, int64_t piv_cap, int64_t* n_piv);

@@ -612,6 +612,28 @@ int orc_bb_add_constraint(const double* base, int rows, int cols, const double* 
     return 0;
 }
 
+/* RoundTableau :552-567 in place (RoundAllTableaux after a child's DoDualSimplex, :1124,:1187). */
+void orc_bb_round_tableau(double* T, int rows, int cols) {
+    Tab t;
+    t.a = T;
+    t.rows = rows;
+    t.cols = cols;
+    tab_round(&t);
+}
+
+/* What ExecuteBranchAndBound does with a popped node before it branches: RoundAllTableaux :1047
+ * (T is rounded IN PLACE), GetObjective :892-897 -> *z, the decision values of
+ * CheckIntegerBasicVar :805-857 / ExtractSolution :899-921 -> vals[nvars]. */
+void orc_bb_node_info(double* T, int rows, int cols, int nvars, double* z, double* vals) {
+    Tab t;
+    t.a = T;
+    t.rows = rows;
+    t.cols = cols;
+    tab_round(&t);
+    if (z) *z = orc_round4(AT(&t, 0, cols - 1));
+    if (vals) decision_values(&t, nvars, vals);
+}
+
 /* DoDualSimplex on one tableau: returns 0/1/2 as do_dual_simplex; `out` gets the last tableau. */
 int orc_bb_dual_simplex(const double* start, int rows, int cols, double* out, int* npiv,
                         int32_t* piv_trace, int64_t piv_cap, int64_t* n_piv) {

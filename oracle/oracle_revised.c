@@ -170,6 +170,156 @@ int orc_revised_solve_trace(int n, int m, const double* objective, const double*
     return st;
 }
 
+/* Entering choice :105-121 over `nonbasic` (nnb indices, any order): the list is sorted
+ * (nonBasicVariables.OrderBy(v => v): stable, values distinct) into `sorted`, then the EPS-band
+ * fold.  Returns the entering index or -1. */
+static int choose_entering(const int* nonbasic, int nnb, int* sorted, int n, const double* rcX,
+                           const double* rcS) {
+    memcpy(sorted, nonbasic, sizeof(int) * nnb);
+    for (int a = 1; a < nnb; a++) { /* insertion sort: the list is almost sorted */
+        int v = sorted[a], k = a - 1;
+        while (k >= 0 && sorted[k] > v) { sorted[k + 1] = sorted[k]; k--; }
+        sorted[k + 1] = v;
+    }
+    int enteringIdx = -1;
+    double bestPosRC = -INFINITY;
+    for (int q = 0; q < nnb; q++) {
+        int vIdx = sorted[q];
+        double rc = (vIdx < n) ? rcX[vIdx] : rcS[vIdx - n];
+        if (rc > EPS) {
+            if (enteringIdx == -1 || rc > bestPosRC + EPS ||
+                (fabs(rc - bestPosRC) <= EPS && vIdx < enteringIdx)) {
+                bestPosRC = rc;
+                enteringIdx = vIdx;
+            }
+        }
+    }
+    return enteringIdx;
+}
+
+/* Ratio test :154-176; fills ratios[m] (:161, :174).  Returns the leaving row or -1. */
+static int ratio_test(int m, const double* xB, const double* u, const int* basic, double* ratios) {
+    int leavingRow = -1;
+    double bestRatio = DBL_MAX;
+    for (int i = 0; i < m; i++) {
+        if (u[i] > EPS) {
+            double ratio = xB[i] / u[i];
+            ratios[i] = ratio; /* :161 */
+            if (ratio < bestRatio - EPS ||
+                (fabs(ratio - bestRatio) <= EPS &&
+                 (leavingRow == -1 || basic[i] < basic[leavingRow]))) {
+                bestRatio = ratio;
+                leavingRow = i;
+            }
+        } else {
+            ratios[i] = INFINITY; /* :174 */
+        }
+    }
+    return leavingRow;
+}
+
+/* reduced costs :96-102 */
+static void reduced_costs(int n, int m, const double* c, const double* A, const double* y,
+                          double* col, double* rcX, double* rcS) {
+    for (int j = 0; j < n; j++) { /* :96-98  rc = c_j - Dot(y, GetColumn(A, j)) */
+        for (int i = 0; i < m; i++) col[i] = A[(size_t)i * n + j];
+        rcX[j] = c[j] - dot(y, col, m);
+    }
+    for (int k = 0; k < m; k++) rcS[k] = -y[k]; /* :100-102 */
+}
+
+/* direction :149-151 */
+static void direction(int n, int m, const double* A, const double* Binv, int enteringIdx,
+                      double* col, double* u) {
+    if (enteringIdx < n) {
+        for (int i = 0; i < m; i++) col[i] = A[(size_t)i * n + enteringIdx];
+        mat_vec(Binv, m, m, col, u);
+    } else {
+        int k = enteringIdx - n;
+        for (int i = 0; i < m; i++) u[i] = Binv[(size_t)i * m + k];
+    }
+}
+
+/*
+ * ONE pass of Solve()'s loop body (:89-215) from a GIVEN state (B^-1, basis) instead of the slack
+ * basis: what tests/test_revised_gpu.py compares lpr_revised_step with at m = 4096 once B^-1 has
+ * filled in (a whole oracle solve to that point would take hours).  c_B is rebuilt from the basis
+ * (:205,211: c_B[i] = c[basic[i]] for structurals, 0 for slacks); the non-basic list is the
+ * complement of the basis (only ever iterated sorted, :108).
+ *   Binv[m*m], basis[m]: in; updated in place when a pivot is made (status ORC_PIVOT_LIMIT = "one
+ *   pivot done, loop continues").  Outputs (pre-pivot, each may be NULL): xB[m], y[m], rcX[n],
+ *   rcS[m], u[m], ratios[m], *entering, *leaving_row.
+ * Returns ORC_OK_OPTIMAL (no entering variable; nothing modified), ORC_INFEASIBLE_BASIS,
+ * ORC_UNBOUNDED, ORC_ENTERING_ALREADY_BASIC, ORC_PIVOT_TOO_SMALL, or ORC_PIVOT_LIMIT.
+ */
+int orc_revised_iterate_from(int n, int m, const double* objective, const double* A,
+                             const double* b, int is_min, double* Binv, int32_t* basis,
+                             double* xB_out, double* y_out, double* rcX_out, double* rcS_out,
+                             double* u_out, double* ratios_out, int32_t* entering,
+                             int32_t* leaving_row) {
+    if (n <= 0 || m <= 0 || !Binv || !basis) return ORC_BAD_ARGUMENT;
+    int status = ORC_PIVOT_LIMIT;
+    double* c = (double*)malloc(sizeof(double) * n);
+    double* cB = (double*)calloc(m, sizeof(double));
+    double* xB = (double*)calloc(m, sizeof(double));
+    double* y = (double*)malloc(sizeof(double) * m);
+    double* rcX = (double*)malloc(sizeof(double) * n);
+    double* rcS = (double*)malloc(sizeof(double) * m);
+    double* col = (double*)malloc(sizeof(double) * m);
+    double* u = (double*)calloc(m, sizeof(double));
+    double* ratios = (double*)malloc(sizeof(double) * m);
+    int* basic = (int*)malloc(sizeof(int) * m);
+    int* nonbasic = (int*)malloc(sizeof(int) * (n + m));
+    int* sorted = (int*)malloc(sizeof(int) * (n + m));
+    char* isb = (char*)calloc((size_t)n + m, 1);
+    int nnb = 0, enteringIdx = -1, leavingRow = -1;
+    for (int j = 0; j < n; j++) c[j] = is_min ? -objective[j] : objective[j]; /* :51 */
+    for (int i = 0; i < m; i++) {
+        basic[i] = basis[i];
+        isb[basic[i]] = 1;
+        cB[i] = basic[i] < n ? c[basic[i]] : 0.0;
+        ratios[i] = INFINITY;
+    }
+    for (int v = 0; v < n + m; v++) if (!isb[v]) nonbasic[nnb++] = v;
+
+    mat_vec(Binv, m, m, b, xB); /* :89 */
+    int infeasible = 0;
+    for (int i = 0; i < m; i++) if (xB[i] < -EPS) { infeasible = 1; break; } /* :90 */
+    if (infeasible) status = ORC_INFEASIBLE_BASIS;
+    else {
+        vec_mat(cB, Binv, m, m, y); /* :93 */
+        reduced_costs(n, m, c, A, y, col, rcX, rcS);
+        enteringIdx = choose_entering(nonbasic, nnb, sorted, n, rcX, rcS);
+        if (enteringIdx == -1) status = ORC_OK_OPTIMAL;
+        else {
+            direction(n, m, A, Binv, enteringIdx, col, u);
+            leavingRow = ratio_test(m, xB, u, basic, ratios);
+            if (leavingRow == -1) status = ORC_UNBOUNDED;
+            else if (basic[leavingRow] == enteringIdx) status = ORC_ENTERING_ALREADY_BASIC;
+            else {
+                double* scratch = (double*)malloc(sizeof(double) * (size_t)m * m);
+                int rc2 = orc_update_binverse(Binv, m, leavingRow, u, scratch); /* :215 */
+                free(scratch);
+                if (rc2 != 0) status = rc2;
+                else basis[leavingRow] = enteringIdx; /* :195 */
+            }
+        }
+    }
+    if (xB_out) memcpy(xB_out, xB, sizeof(double) * m);
+    if (status != ORC_INFEASIBLE_BASIS) {
+        if (y_out) memcpy(y_out, y, sizeof(double) * m);
+        if (rcX_out) memcpy(rcX_out, rcX, sizeof(double) * n);
+        if (rcS_out) memcpy(rcS_out, rcS, sizeof(double) * m);
+    }
+    if (u_out) memcpy(u_out, u, sizeof(double) * m);
+    if (ratios_out) memcpy(ratios_out, ratios, sizeof(double) * m);
+    if (entering) *entering = enteringIdx;
+    if (leaving_row) *leaving_row = leavingRow;
+    free(c); free(cB); free(xB); free(y); free(rcX); free(rcS); free(col); free(u); free(ratios);
+    free(basic); free(nonbasic); free(sorted); free(isb);
+    return status;
+}
+
 static int revised_core(int n, int m, const double* objective, const double* A, const double* b,
                         int is_min, int64_t max_iter, double* x, double* finalZ, int32_t* basis,
                         double* Binv_out, double* xB_out, int32_t* log_row, int32_t* log_enter,
@@ -211,32 +361,10 @@ static int revised_core(int n, int m, const double* objective, const double* A, 
 
         vec_mat(cB, Binv, m, m, y); /* :93 */
 
-        for (int j = 0; j < n; j++) { /* :96-98  rc = c_j - Dot(y, GetColumn(A, j)) */
-            for (int i = 0; i < m; i++) col[i] = A[(size_t)i * n + j];
-            rcX[j] = c[j] - dot(y, col, m);
-        }
-        for (int k = 0; k < m; k++) rcS[k] = -y[k]; /* :100-102 */
+        reduced_costs(n, m, c, A, y, col, rcX, rcS); /* :96-102 */
 
         /* :105-121 entering: nonBasicVariables.OrderBy(v => v) (stable; values are distinct) */
-        memcpy(sorted, nonbasic, sizeof(int) * nnb);
-        for (int a = 1; a < nnb; a++) { /* insertion sort: the list is almost sorted */
-            int v = sorted[a], k = a - 1;
-            while (k >= 0 && sorted[k] > v) { sorted[k + 1] = sorted[k]; k--; }
-            sorted[k + 1] = v;
-        }
-        int enteringIdx = -1;
-        double bestPosRC = -INFINITY;
-        for (int q = 0; q < nnb; q++) {
-            int vIdx = sorted[q];
-            double rc = (vIdx < n) ? rcX[vIdx] : rcS[vIdx - n];
-            if (rc > EPS) {
-                if (enteringIdx == -1 || rc > bestPosRC + EPS ||
-                    (fabs(rc - bestPosRC) <= EPS && vIdx < enteringIdx)) {
-                    bestPosRC = rc;
-                    enteringIdx = vIdx;
-                }
-            }
-        }
+        int enteringIdx = choose_entering(nonbasic, nnb, sorted, n, rcX, rcS);
 
         if (enteringIdx == -1) { /* :124-146: ExtractSolution, then the "Optimal" snapshot */
             status = ORC_OK_OPTIMAL;
@@ -252,32 +380,8 @@ static int revised_core(int n, int m, const double* objective, const double* A, 
         }
         if (max_iter > 0 && iteration >= max_iter) { status = ORC_PIVOT_LIMIT; break; }
 
-        /* :149-151 direction */
-        if (enteringIdx < n) {
-            for (int i = 0; i < m; i++) col[i] = A[(size_t)i * n + enteringIdx];
-            mat_vec(Binv, m, m, col, u);
-        } else {
-            int k = enteringIdx - n;
-            for (int i = 0; i < m; i++) u[i] = Binv[(size_t)i * m + k];
-        }
-
-        /* :154-176 ratio test */
-        int leavingRow = -1;
-        double bestRatio = DBL_MAX;
-        for (int i = 0; i < m; i++) {
-            if (u[i] > EPS) {
-                double ratio = xB[i] / u[i];
-                ratios[i] = ratio; /* :161 */
-                if (ratio < bestRatio - EPS ||
-                    (fabs(ratio - bestRatio) <= EPS &&
-                     (leavingRow == -1 || basic[i] < basic[leavingRow]))) {
-                    bestRatio = ratio;
-                    leavingRow = i;
-                }
-            } else {
-                ratios[i] = INFINITY; /* :174 */
-            }
-        }
+        direction(n, m, A, Binv, enteringIdx, col, u); /* :149-151 */
+        int leavingRow = ratio_test(m, xB, u, basic, ratios); /* :154-176 */
         if (leavingRow == -1) { status = ORC_UNBOUNDED; break; } /* :178-179 */
         int leavingVar = basic[leavingRow];
         if (leavingVar == enteringIdx) { status = ORC_ENTERING_ALREADY_BASIC; break; } /* :182-183 */
@@ -310,11 +414,7 @@ static int revised_core(int n, int m, const double* objective, const double* A, 
         if (tr && tr->buf) { /* :217-247: post-pivot quantities, then the snapshot */
             mat_vec(Binv, m, m, b, xB);
             vec_mat(cB, Binv, m, m, y);
-            for (int j = 0; j < n; j++) {
-                for (int i = 0; i < m; i++) col[i] = A[(size_t)i * n + j];
-                rcX[j] = c[j] - dot(y, col, m);
-            }
-            for (int k = 0; k < m; k++) rcS[k] = -y[k];
+            reduced_costs(n, m, c, A, y, col, rcX, rcS);
             memset(xtmp, 0, sizeof(double) * n); /* ComputeOriginalZFromCurrentBasis :253-262 */
             for (int i = 0; i < m; i++)
                 if (basic[i] < n) xtmp[basic[i]] = dotnet_max0(xB[i]);

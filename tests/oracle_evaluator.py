@@ -11,22 +11,17 @@ class OracleEvaluator:
         self.n = nvars
         self.nodes = {0: np.array(root, dtype=np.float64)}
         self.next_id = 1
-        self.r4 = np.vectorize(oracle.round4, otypes=[np.float64])
+        self.r4 = oracle.bb_round_tableau
 
     def node_info(self, ids):
+        """RoundAllTableaux :1047, GetObjective :892-897, decision values :805-857 -- by the C
+        oracle (orc_bb_node_info; a Python loop over 512 x 577 entries per node is too slow for
+        the bench-sized instance)."""
         zs, vals = [], []
         for i in ids:
-            T = self.r4(self.nodes[i])
+            T, z, v = self.o.bb_node_info(self.nodes[i], self.n)
             self.nodes[i] = T
-            zs.append(self.o.round4(T[0, -1]))
-            v = []
-            for k in range(self.n):
-                val = 0.0
-                for j in range(T.shape[0]):
-                    if abs(self.o.round4(T[j, k]) - 1.0) <= 1e-6:
-                        val = self.o.round4(T[j, -1])
-                        break
-                v.append(val)
+            zs.append(z)
             vals.append(v)
         return np.array(zs), np.array(vals).reshape(len(ids), self.n)
 
@@ -38,8 +33,12 @@ class OracleEvaluator:
             con[self.n] = b
             con[self.n + 1] = float(kd)
             adj = self.o.bb_add_constraint(self.nodes[p], con)
-            rc, last, npiv, _ = self.o.bb_dual_simplex(adj)
+            rc, last, npiv, trace = self.o.bb_dual_simplex(adj)
+            # pivots as lpr_bb_expand counts them (tableaux.Count - 1 at the exit, also for a child
+            # that ends infeasible): pivots performed minus a dropped last tableau (:395-400)
+            done = sum(1 for t in trace if t[0] < 2) - sum(1 for t in trace if t[0] == 2)
             if rc == 0:
+                assert done == npiv
                 self.nodes[self.next_id] = self.r4(last)
                 child.append(self.next_id)
                 self.next_id += 1
@@ -48,7 +47,7 @@ class OracleEvaluator:
             else:
                 child.append(-1)
                 st.append(3 if rc == 1 else 4)
-                piv.append(npiv if rc == 1 else 0)
+                piv.append(done if rc == 1 else 0)
         return np.array(child), np.array(st), np.array(piv)
 
     def release(self, ids):

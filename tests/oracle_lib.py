@@ -207,6 +207,22 @@ class Oracle:
                                        con.shape[0], _dp(out))
         return out
 
+    def bb_round_tableau(self, T):
+        """RoundTableau :552-567 on a copy."""
+        T = np.array(T, dtype=np.float64, order="C", copy=True)
+        self.lib.orc_bb_round_tableau.restype = None
+        self.lib.orc_bb_round_tableau(_dp(T), T.shape[0], T.shape[1])
+        return T
+
+    def bb_node_info(self, T, nvars):
+        """A popped node: (rounded tableau :1047, z :892-897, decision values :805-857)."""
+        T = np.array(T, dtype=np.float64, order="C", copy=True)
+        z = C.c_double()
+        vals = np.zeros(max(nvars, 1))
+        self.lib.orc_bb_node_info.restype = None
+        self.lib.orc_bb_node_info(_dp(T), T.shape[0], T.shape[1], nvars, C.byref(z), _dp(vals))
+        return T, z.value, vals[:nvars]
+
     def bb_dual_simplex(self, start, piv_cap=1 << 14):
         start = np.ascontiguousarray(start, dtype=np.float64)
         out = np.zeros_like(start)
@@ -253,6 +269,25 @@ class Oracle:
         k = min(it.value, log_cap)
         return dict(status=st, iterations=it.value, x=x, z=z.value, basis=basis, Binv=Binv,
                     xB=xB, log=np.stack([lr[:k], le[:k], ll[:k]], axis=1))
+
+    def revised_iterate_from(self, objective, A, b, Binv, basis, is_min=False):
+        """One pass of Solve()'s loop (:89-215) from a given state.  Binv / basis are copied; the
+        updated ones are returned with the pre-pivot vectors."""
+        obj = np.ascontiguousarray(objective, dtype=np.float64)
+        A = np.ascontiguousarray(A, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        m, n = A.shape
+        Binv = np.array(Binv, dtype=np.float64, order="C", copy=True)
+        basis = np.array(basis, dtype=np.int32, copy=True)
+        xB, y, rcX, rcS, u, ratios = (np.zeros(m), np.zeros(m), np.zeros(n), np.zeros(m),
+                                      np.zeros(m), np.zeros(m))
+        ent, lrow = C.c_int32(), C.c_int32()
+        st = self.lib.orc_revised_iterate_from(n, m, _dp(obj), _dp(A), _dp(b), 1 if is_min else 0,
+                                               _dp(Binv), _ip(basis), _dp(xB), _dp(y), _dp(rcX),
+                                               _dp(rcS), _dp(u), _dp(ratios), C.byref(ent),
+                                               C.byref(lrow))
+        return dict(status=st, entering=ent.value, leaving_row=lrow.value, xB=xB, y=y, rcX=rcX,
+                    rcS=rcS, u=u, ratios=ratios, Binv=Binv, basis=basis)
 
     def revised_trace(self, objective, A, b, is_min=False, max_iter=0, cap=64):
         """Every CaptureSnapshot (:294-387) as a dict of numbers (layout: oracle_revised.c)."""

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 import bb_cases
+from oracle_evaluator import OracleEvaluator
 
 pytestmark = pytest.mark.gpu
 
@@ -284,3 +285,125 @@ def test_level_sync_two_ranks_through_the_abi(engine, oracle):
             assert bits(r["z"]) == bits(one["z"]) == bits(ref["z"])
             assert [bits(v) for v in r["x"]] == [bits(v) for v in ref["x"]]
             assert tuple(r["path"]) == tuple(one["path"])
+
+
+def _fault_worker(rank, world, port, case_name, out_dir, fault):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["LPR_BB_INJECT_FAULT"] = fault  # "<rank>:<level>", read by the library
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import lpr_381_group_v22_amd as pkg
+    from lpr_381_group_v22_amd import _native as N
+    from oracle_lib import Oracle
+    import bb_cases as cases
+    orc = Oracle()
+    obj, cons = dict(cases.all_bb_cases())[case_name]
+    st, T, n = cases.primal_final_tableau(orc, obj, cons)
+
+    def arm(v):
+        t = torch.tensor(v, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.tolist()
+
+    def gather(b):
+        out = [None] * world
+        dist.all_gather_object(out, b)
+        return out
+
+    eng = pkg.Engine(0)
+    comm = pkg.Comm.custom(rank, world, arm, gather)
+    tree = pkg.BranchBoundTree.from_array(eng, T, n, max_depth=64)
+    out = {"status": None, "message": ""}
+    try:
+        pkg.solve_level_sync_native(tree, comm)
+        out["status"] = 0
+    except N.EngineError as exc:
+        out["status"] = exc.status
+        out["message"] = str(exc)
+    out["calls"] = comm.info()
+    tree.destroy()
+    comm.destroy()
+    eng.close()
+    with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
+        json.dump(out, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_level_sync_failure_on_one_rank_is_returned_by_every_rank(engine, oracle, world):
+    """A rank-local failure inside lpr_bb_solve_level_sync (injected: LPR_BB_INJECT_FAULT) must not
+    leave the peers in the level's collective for ever: it rides in that all-reduce (4th MAX slot),
+    every rank returns LPR_DEVICE_ERROR from the same level and nobody enters the final gather."""
+    import socket
+    import tempfile
+    import time
+    import torch.multiprocessing as mp
+    case, fault_level = "binary_10v2c_s4", 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    with tempfile.TemporaryDirectory() as d:
+        ctx = mp.spawn(_fault_worker, args=(world, port, case, d, f"{world - 1}:{fault_level}"),
+                       nprocs=world, join=False)
+        t_end = time.monotonic() + 240
+        while not ctx.join(timeout=1.0):
+            if time.monotonic() > t_end:
+                for p in ctx.processes:
+                    if p.is_alive():
+                        p.kill()
+                pytest.fail("ranks still running: a peer is waiting in a collective")
+        res = [json.load(open(os.path.join(d, f"rank{r}.json"))) for r in range(world)]
+    for r, out in enumerate(res):
+        assert out["status"] == -2, out  # LPR_DEVICE_ERROR on EVERY rank
+        assert out["calls"]["allreduce_calls"] == fault_level + 1, out
+        assert out["calls"]["allgather_calls"] == 0, out
+        assert ("injected fault" if r == world - 1 else "another rank failed") in out["message"], out
+
+
+def test_level_sync_max_levels_below_the_depth_scores_the_last_frontier(engine, oracle):
+    """with max_levels smaller than the tree depth the children solved by the last level
+    are still scored (integer check + incumbent) and the status says the search was cut
+    (LPR_BB_DEPTH_CAP); the library and the Python mirror agree."""
+    from lpr_381_group_v22_amd import (BranchBoundTree, solve_level_sync_native,
+                                       solve_level_synchronous)
+    from lpr_381_group_v22_amd import _native as N
+    for name, T, n, ref in _terminating_cases(oracle)[:4]:
+        full = solve_level_synchronous(OracleEvaluator(oracle, T, n), n)
+        for L in (1, 2, len(full["path"]) if full["found"] else 3):
+            if L < 1:
+                continue
+            a = BranchBoundTree.from_array(engine, T, n, max_depth=64)
+            got = solve_level_sync_native(a, max_levels=L)
+            a.destroy()
+            py = solve_level_synchronous(OracleEvaluator(oracle, T, n), n, max_levels=L)
+            assert got["status"] == py["status"], (name, L)
+            assert got["processed"] == py["processed"] and got["levels"] == py["levels"], (name, L)
+            assert got["found"] == py["found"] and got["pivots"] == py["pivots"], (name, L)
+            if got["found"]:
+                assert bits(got["z"]) == bits(py["z"]) and got["path"] == tuple(py["path"])
+            if full["found"] and L == len(full["path"]) and full["levels"] > L:
+                # the optimum sits exactly at depth max_levels: found, same z as the full search
+                assert got["found"] and bits(got["z"]) == bits(full["z"]), name
+    assert N.LPR_BB_DEPTH_CAP == 7
+
+
+def test_comm_outlives_its_engine_safely(oracle):
+    """lpr_engine_close with a live RCCL communicator orphans it (no dangling engine
+    pointer): collectives are refused, lpr_comm_destroy stays safe."""
+    import lpr_381_group_v22_amd as pkg
+    from lpr_381_group_v22_amd import _native as N
+    eng = pkg.Engine(0)
+    comm = pkg.Comm.rccl(eng, 0, 1, pkg.Comm.unique_id())
+    assert comm.all_reduce_max([2.0]) == [2.0]
+    eng.close()
+    with pytest.raises(N.EngineError):
+        comm.all_reduce_max([1.0])
+    comm.destroy()

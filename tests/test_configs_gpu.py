@@ -122,3 +122,74 @@ def test_config3_bb_hundreds_of_live_subproblems(engine, oracle):
     if ref["found"]:
         assert [bits(v) for v in got["x"]] == [bits(v) for v in ref["x"]]
         assert tuple(got["path"]) == tuple(ref["path"])
+
+
+class _Recording:
+    """Evaluator wrapper that keeps what every level saw: z and decision values of every node."""
+
+    def __init__(self, inner):
+        self.inner, self.levels, self.max_batch = inner, [], 0
+
+    def node_info(self, ids):
+        zs, vals = self.inner.node_info(ids)
+        self.levels.append((np.array(zs, dtype=np.float64).copy(),
+                            np.array(vals, dtype=np.float64).copy()))
+        return zs, vals
+
+    def expand(self, p, v, b, k):
+        self.max_batch = max(self.max_batch, len(p))
+        return self.inner.expand(p, v, b, k)
+
+    def release(self, ids):
+        return self.inner.release(ids)
+
+
+def test_config3_bench_instance_six_levels_vs_oracle(engine, oracle):
+    """Branch & Bound at the size bench.py runs -- the 512-variable binary
+    programme of bench.bb_instance (577 x 1089 root, BranchBoundSimplexSolver.cs:289-468,694-803
+    on M-sized tableaux) -- six levels (127 nodes scored, 126 children solved, 64 live at the
+    widest level) against the oracle-backed evaluator: z and all 512 decision values of EVERY node
+    of EVERY level bit for bit, node / pivot counts, and the library's own driver
+    (lpr_bb_solve_level_sync) against both."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import bb_instance
+    import lpr_381_group_v22_amd as pkg
+    from lpr_381_group_v22_amd import (BranchBoundTree, Constraint, solve_level_sync_native,
+                                       solve_level_synchronous)
+    nv, nc, levels = 512, 64, 6
+    c, A, b = bb_instance(nv, nc, 7)
+    cons = [Constraint(A[i].tolist(), "<=", float(b[i])) for i in range(nc)]
+    for i in range(nv):  # Program.cs:372-382
+        co = [0.0] * (nv + 3)
+        co[i] = 1.0
+        co[nv + 1] = 1.0
+        cons.append(Constraint(co, "<=", 1.0))
+    primal = pkg.PrimalSimplexSolver(c.tolist(), cons, True, engine=engine, snapshots="none")
+    primal.Solve()
+    T = primal.tableau.read()
+    assert T.shape == (577, 1089)
+    tree = BranchBoundTree.from_tableau(primal.tableau, nv, max_depth=levels + 2)
+    gpu = _Recording(tree)
+    got = solve_level_synchronous(gpu, nv, max_levels=levels)
+    tree.destroy()
+    cpu = _Recording(OracleEvaluator(oracle, T, nv))
+    ref = solve_level_synchronous(cpu, nv, max_levels=levels)
+    assert len(gpu.levels) == len(cpu.levels) == levels + 1
+    for lv, ((gz, gv), (cz, cv)) in enumerate(zip(gpu.levels, cpu.levels)):
+        assert gz.shape == cz.shape and gz.tobytes() == cz.tobytes(), f"z differs at level {lv}"
+        assert gv.tobytes() == cv.tobytes(), f"decision values differ at level {lv}"
+    assert gpu.max_batch == cpu.max_batch >= 64
+    for k in ("processed", "pivots", "levels", "found", "status"):
+        assert got[k] == ref[k], k
+    assert got["processed"] == 127 and bits(got["z"]) == bits(ref["z"])
+    tree2 = BranchBoundTree.from_tableau(primal.tableau, nv, max_depth=levels + 2)
+    nat = solve_level_sync_native(tree2, max_levels=levels)
+    tree2.destroy()
+    for k in ("processed", "pivots", "levels", "found", "status"):
+        assert nat[k] == ref[k], k
+    assert bits(nat["z"]) == bits(ref["z"])
+    if ref["found"]:
+        assert [bits(v) for v in nat["x"]] == [bits(v) for v in ref["x"]]
+        assert nat["path"] == tuple(ref["path"])

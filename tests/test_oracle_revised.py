@@ -167,3 +167,35 @@ def test_n3_restatement_against_the_host_formatter():
         [round(v, 3) + 0.0005 for v in rng.randn(100)]
     for v in vals:
         assert py_n3(v) == N3(v), repr(v)
+
+
+@pytest.mark.parametrize("name,case", revised_cases(), ids=[c[0] for c in revised_cases()])
+def test_iterate_from_state_chains_into_the_whole_solve(oracle, name, case):
+    """orc_revised_iterate_from (one pass of Solve()'s loop from a GIVEN B^-1 / basis: what the
+    m = 4096 GPU test compares lpr_revised_step with) chained from the slack basis is the whole
+    solve: same log, basis, B^-1 and, per iteration, the trace's pre-pivot vectors."""
+    obj, cons, is_min = case
+    A, b = flat(cons)
+    m, n = A.shape
+    ref = oracle.revised_solve(obj, A, b, is_min, max_iter=40)
+    tr = oracle.revised_trace(obj, A, b, is_min, max_iter=40, cap=48)
+    Binv, basis = np.eye(m), np.arange(n, n + m, dtype=np.int32)
+    k = 0
+    while True:
+        it = oracle.revised_iterate_from(obj, A, b, Binv, basis, is_min)
+        if it["status"] != 5 or k >= 40:
+            break
+        assert (it["leaving_row"], it["entering"], int(basis[it["leaving_row"]])) == \
+            tuple(ref["log"][k].tolist()), k
+        snap = tr["snapshots"][k]
+        assert it["u"].tobytes() == snap["u_pre"].tobytes()
+        assert it["ratios"].tobytes() == snap["ratios_pre"].tobytes()
+        Binv, basis = it["Binv"], it["basis"]
+        assert Binv.tobytes() == snap["BInv"].tobytes()
+        k += 1
+    assert k == ref["iterations"]
+    if ref["status"] != 5:
+        assert it["status"] == ref["status"]
+    assert basis.tolist() == ref["basis"].tolist() and Binv.tobytes() == ref["Binv"].tobytes()
+    if ref["status"] in (0, 5):
+        assert it["xB"].tobytes() == ref["xB"].tobytes()

@@ -234,7 +234,8 @@ def test_config3_m4096_n8192_iterations_and_product(engine, oracle):
     (about 3 s of one core each) -- status, pivot log, basis, x_B and all of B^-1 bit for bit -- then,
     after 150 more iterations on the device have filled B^-1 in, the MFMA product B^-1 * A
     (CaptureSnapshot :360) against the oracle's literal loop on a 64-row slice, with the stated
-    tolerance |err| <= 1e-9 * (|B^-1| |A|)_ij + 1e-12."""
+    tolerance |err| <= 1e-9 * (|B^-1| |A|)_ij + 1e-12; then two lpr_revised_step from that DENSE
+    state against the oracle's loop body, every vector bit for bit."""
     from lpr_381_group_v22_amd import RevisedState
     m, n, seed, iters = 4096, 8192, 0, 3
     c, A, b = oracle.gen_dense_lp(m, n, seed)
@@ -265,6 +266,39 @@ def test_config3_m4096_n8192_iterations_and_product(engine, oracle):
             e = np.zeros(m)
             e[row] = 1.0
             assert np.abs(got[:, v] - e).max() < 1e-6
+    del got, want
+    # ---- the order-faithful sums with DENSE operands against the oracle.
+    # From this filled-in state (B^-1, basis read back) the oracle runs the loop body of Solve()
+    # (:89-215, orc_revised_iterate_from: ~2 s per pass) and lpr_revised_step must agree bit for
+    # bit: entering, direction u = B^-1 a_e (:149-151), ratios (:154-176), leaving row, the
+    # updated B^-1 (:264-275), and the post-pivot x_B / y / reduced costs (:218-227), which are
+    # the next pass's x_B = B^-1 b (:89), y = c_B B^-1 (:93), rc (:96-102) of the oracle.
+    c, A, b = oracle.gen_dense_lp(m, n, seed)
+    nnz = int((np.abs(Binv) >= 1e-9).sum())
+    assert nnz > 40 * m, "B^-1 has not filled in"
+    basis0 = st.basis()
+    for rep in range(2):
+        o0 = oracle.revised_iterate_from(c, A, b, Binv, basis0, False)
+        assert o0["status"] == 5
+        info = st.step()
+        y, rc, u, ratios, bpre, xb = st.snapshot()
+        assert info.status == 5 and info.entering == o0["entering"], rep
+        assert info.leaving_row == o0["leaving_row"], rep
+        assert info.leaving_var == int(basis0[o0["leaving_row"]]), rep
+        assert bpre.tolist() == basis0.tolist()
+        assert u.tobytes() == o0["u"].tobytes(), rep
+        assert ratios.tobytes() == o0["ratios"].tobytes(), rep
+        e = o0["entering"]
+        rc_pre = o0["rcX"][e] if e < n else o0["rcS"][e - n]
+        assert bits(info.entering_rc_pre) == bits(rc_pre), rep
+        Binv = st.binv()
+        assert Binv.tobytes() == o0["Binv"].tobytes(), rep
+        basis0 = st.basis()
+        assert basis0.tolist() == o0["basis"].tolist(), rep
+        o1 = oracle.revised_iterate_from(c, A, b, Binv, basis0, False)  # pre-values of the next pass
+        assert xb.tobytes() == o1["xB"].tobytes(), rep
+        assert y.tobytes() == o1["y"].tobytes(), rep
+        assert rc[:n].tobytes() == o1["rcX"].tobytes() and rc[n:].tobytes() == o1["rcS"].tobytes()
     st.destroy()
 
 
