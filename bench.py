@@ -514,13 +514,21 @@ def run_sens(args, D: Dist):
     if res.status != 0:
         raise SystemExit(f"primal solve ended with status {res.status}")
     sens = SensState.from_tableau(tab, n)
+    want_cpu = D.world == 1 and args.cpu_pivots != 0
+    if want_cpu:  # what the CPU leg starts from: the optimal tableau itself (one 403 MB read-back)
+        T_opt, basis_opt = tab.read(), tab.basis()
+        x_opt, z_opt = tab.extract_solution(n)
     tab.destroy()
 
-    def edit(step):
+    def new_rhs(cur):
+        return cur - 0.05 * abs(cur) - 1.0
+
+    def edit(step, handle=None):
+        h = handle or sens
         k = 1 + (step * 997) % m
-        cur = float(sens.read_block(k, 1, C - 1, 1)[0, 0])
-        oc = sens.change_rhs(k, cur - 0.05 * abs(cur) - 1.0)
-        return oc, sens.shape()[5]
+        cur = float(h.read_block(k, 1, C - 1, 1)[0, 0])
+        oc = h.change_rhs(k, new_rhs(cur))
+        return oc, h.shape()[5]
 
     for w in range(W):
         edit(w)
@@ -557,6 +565,44 @@ def run_sens(args, D: Dist):
                          "traffic": None},
             "cpu_baseline": None,
         }
+        if want_cpu:
+            # the C oracle of SensitivityAnalyzer.ChangeRHS (:427-470: DualSimplexIfNeeded +
+            # ReOptimize, one thread) on the SAME optimal tableau, the first edits of the same
+            # sequence (about 15 s), then those edits again on a fresh device handle built from the
+            # same bytes: outcome and pivot count of every edit, and the final Z bits, compared
+            orc = _oracle()
+            o = orc.sens(T_opt, x_opt, z_opt, basis_opt)
+            c0 = time.perf_counter()
+            cpu_out, cpu_piv, nlog = [], [], 0
+            for step in range(min(K + W, 64)):
+                k = 1 + (step * 997) % m
+                cur = float(o.state()["T"][k, C - 1])
+                oc = o.change_rhs(k, new_rhs(cur))
+                q = len(o.log())
+                cpu_out.append(int(oc))
+                cpu_piv.append(q - nlog)
+                nlog = q
+                if time.perf_counter() - c0 > 15.0:
+                    break
+            cdt = time.perf_counter() - c0
+            chk = SensState.create(eng, T_opt, x_opt, z_opt)
+            gpu_out, gpu_piv = [], []
+            for step in range(len(cpu_out)):
+                oc, pp = edit(step, chk)
+                gpu_out.append(int(oc))
+                gpu_piv.append(int(pp))
+            same = gpu_out == cpu_out and gpu_piv == cpu_piv and \
+                np.float64(chk.shape()[4]).tobytes() == np.float64(o.state()["z"]).tobytes()
+            chk.destroy()
+            out["cpu_baseline"] = {
+                "value": round(sum(cpu_piv) / cdt, 3), "unit": "pivots/s", "cores": 1,
+                "kind": "port",
+                "sample": f"first {len(cpu_out)} ChangeRHS edits of the same sequence on the same "
+                          f"optimal tableau ({sum(cpu_piv)} re-solve pivots), C oracle of "
+                          f"SensitivityAnalyzer.cs:98-208,427-470, 1 thread, incl. reading the "
+                          f"row's RHS; cpu: {_cpu_model()}",
+                "edits_per_s": round(len(cpu_out) / cdt, 3),
+                "outcomes_and_pivots_match_gpu": bool(same)}
     sens.destroy()
     eng.close()
     return out

@@ -65,12 +65,12 @@ int comm_world(const lpr_comm* c) { return c ? c->world : 1; }
 
 // v[0..n) <- element-wise maximum over all ranks
 int comm_all_reduce_max(lpr_comm* c, double* v, int n) {
-    if (!c || (c->world == 1 && !c->nccl && !c->ar)) return LPR_OK_OPTIMAL;
-    if (n < 1 || n > 64) return LPR_BAD_ARGUMENT;
-    if (c->orphaned) {
+    if (c && c->orphaned) {
         set_error("lpr_comm: the engine of this communicator has been closed");
         return LPR_BAD_ARGUMENT;
     }
+    if (!c || (c->world == 1 && !c->nccl && !c->ar)) return LPR_OK_OPTIMAL;
+    if (n < 1 || n > 64) return LPR_BAD_ARGUMENT;
     c->allreduce_calls += 1;
     if (c->ar) {
         if (c->ar(c->user, v, n) != 0) {
@@ -90,13 +90,13 @@ int comm_all_reduce_max(lpr_comm* c, double* v, int n) {
 
 // recv[world * bytes] <- send[bytes] of every rank, in rank order
 int comm_all_gather(lpr_comm* c, const void* send, void* recv, int bytes) {
+    if (c && c->orphaned) {
+        set_error("lpr_comm: the engine of this communicator has been closed");
+        return LPR_BAD_ARGUMENT;
+    }
     if (!c || (c->world == 1 && !c->nccl && !c->ag)) {
         std::memcpy(recv, send, (size_t)bytes);
         return LPR_OK_OPTIMAL;
-    }
-    if (c->orphaned) {
-        set_error("lpr_comm: the engine of this communicator has been closed");
-        return LPR_BAD_ARGUMENT;
     }
     c->allgather_calls += 1;
     if (c->ag) {

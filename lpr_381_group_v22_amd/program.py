@@ -207,7 +207,10 @@ def run_option(parser: InputFileParser, choice: str, out_path: str = "data/outpu
         class _Tee(io.TextIOBase):
             def write(self, t):
                 sys.__stdout__.write(t)
-                buf.write(t)
+                # print() sends its line terminator as a write of its own: that one is the
+                # Console.WriteLine terminator (Environment.NewLine in the C#'s StringWriter);
+                # a "\n" INSIDE a string stays what the C# literal holds
+                buf.write(NL if t == "\n" else t)
                 return len(t)
 
         with redirect_stdout(_Tee()):

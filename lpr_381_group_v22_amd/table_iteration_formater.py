@@ -12,7 +12,7 @@ PARITY UNPINNED: the reference holds no formatted output to check these strings 
 from __future__ import annotations
 
 import math
-from decimal import ROUND_HALF_UP, Decimal
+from decimal import ROUND_HALF_UP, Context, Decimal
 from typing import Optional, Sequence
 
 import numpy as np
@@ -31,7 +31,8 @@ def format_fixed(v: float, decimals: int) -> str:
     if math.isinf(v):
         return "Infinity" if v > 0 else "-Infinity"
     q = Decimal(1).scaleb(-decimals)
-    d = _dec15(v).quantize(q, rounding=ROUND_HALF_UP)
+    # (a context of its own: the default 28 digits cannot hold 1e300 at three decimals)
+    d = _dec15(v).quantize(q, rounding=ROUND_HALF_UP, context=Context(prec=700))
     if d == 0:
         d = abs(d)  # "-0.000" never appears on .NET Framework
     return format(d, "f")

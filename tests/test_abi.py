@@ -37,6 +37,28 @@ def test_header_and_binding_agree(native):
     assert sorted(native.SIGNATURES) == decl
 
 
+def test_csharp_binding_declares_every_export_exactly_once():
+    """integration/csharp/NativeMethods.cs (the P/Invoke side a maintainer adds to the reference,
+    uncompiled here: no C# toolchain) must declare every entry point of include/lpr_engine.h once
+    -- a duplicate is a CS0111 compile error, a missing one a lagging binding."""
+    cs = open(os.path.join(ROOT, "integration", "csharp", "NativeMethods.cs")).read()
+    have = re.findall(r"static extern \w+ (lpr_[a-z0-9_]+)\(", cs)
+    assert sorted(have) == declared_functions()
+    assert len(have) == len(set(have)), [h for h in set(have) if have.count(h) > 1]
+    # every DllImport'd status-returning call of the wrappers is checked or its value used
+    gs = open(os.path.join(ROOT, "integration", "csharp", "GpuSolvers.cs")).read()
+    assert "NotImplementedException" not in gs, "the drop-in must not ship a stub on its default path"
+    for name in set(re.findall(r"NativeMethods\.(lpr_[a-z0-9_]+)\(", gs)):
+        assert name in have, name
+    eng = dict(re.findall(r"LPR_([A-Z_]+)\s*=\s*(-?\d+)", open(HEADER).read()))
+    csn = dict(re.findall(r"(\w+) = (-?\d+)", re.search(r"enum LprStatus\s*{(.*?)}", cs, re.S).group(1)))
+    assert sorted(int(v) for v in csn.values()) == sorted(
+        int(v) for k, v in eng.items() if k in ("OK_OPTIMAL", "UNBOUNDED", "INFEASIBLE_BASIS",
+                                               "PIVOT_TOO_SMALL", "ENTERING_ALREADY_BASIC",
+                                               "PIVOT_LIMIT", "BB_NODE_CAP", "BB_DEPTH_CAP",
+                                               "BAD_ARGUMENT", "DEVICE_ERROR", "OUT_OF_MEMORY"))
+
+
 def test_library_exports_every_declared_symbol(native):
     lib = ctypes.CDLL(native.LIB_PATH)
     for name in declared_functions():

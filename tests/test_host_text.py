@@ -103,3 +103,40 @@ def test_vectorised_node_scoring_equals_scalar_rules():
         assert all_int[q] == all(bb._is_integer(t) for t in vals[q]), q
     xs = np.concatenate([rng.uniform(-50, 50, 500), [0.00005, 2.5, 3.5, -2.5, 1e16, 0.49999999999999994]])
     assert [bb._round4(float(x)) for x in xs] == bb._round4_np(xs).tolist()
+
+
+def test_two_independent_number_formatters_agree():
+    """Row f2: the product's {v:F3} / {v:F6} / double.ToString() mirrors (decimal-module based)
+    against the test-side restatement (digit-string arithmetic, tests/ref_py_text.py) on ties,
+    carries, zeros, huge / tiny magnitudes and 40 000 random doubles."""
+    import numpy as np
+    from lpr_381_group_v22_amd import table_iteration_formater as f
+    from lpr_381_group_v22_amd.program import dotnet_double_to_string
+    from ref_py_text import py_double_to_string, py_fixed
+    special = [0.0, -0.0, 2.0005, 0.0005, -0.0004, -0.0005, 0.9995, 9.9995, 99.9995, 999.9995,
+               -999.9995, 1e15, 1.5e15, 1e16, 123456789012345678.0, 1e-5, 9.99999e-6, 1e-4,
+               1.23456789012345678, 15.4, 15.399999999999999, 0.1, 0.2, 0.30000000000000004,
+               1e300, -1e300, 5e-324, 0.49999999999999994, 0.0049999999999999999, 0.0015,
+               0.0025, 1.0005, 1.0015, 1.0025, float("inf"), float("-inf"), float("nan"),
+               4.35, 4.345, 2.675, 1.005, 100.0, -100.0, 1234567.0004999, 0.00049999999999999]
+    rng = np.random.RandomState(11)
+    rnd = np.concatenate([rng.uniform(-1000, 1000, 20000), rng.uniform(-1, 1, 10000) ** 5,
+                          np.round(rng.uniform(-50, 50, 10000), 4)])
+    for v in special + rnd.tolist():
+        assert f.F3(v) == py_fixed(v, 3), v
+        assert f.F6(v) == py_fixed(v, 6), v
+        assert dotnet_double_to_string(v) == py_double_to_string(v), v
+
+
+def test_two_independent_table_formatters_agree():
+    """TableIterationFormater.Format (:22-48): product mirror vs test-side restatement, with and
+    without row labels, on a tableau holding ties and negative zeros."""
+    import numpy as np
+    from lpr_381_group_v22_amd import table_iteration_formater as f
+    from ref_py_text import py_format_table
+    rng = np.random.RandomState(3)
+    T = np.round(rng.uniform(-20, 20, size=(5, 9)), 4)
+    T[0, 0], T[1, 1], T[2, 2], T[3, 3] = -0.0, 2.0005, -0.0004, 1e7
+    for nv in (2, 4, 8):
+        assert f.Format(T, nv, "Before pivot") == py_format_table(T.tolist(), nv, "Before pivot")
+    assert f.Format(T, 3, "x", ["a", "b"]) == py_format_table(T.tolist(), 3, "x", ["a", "b"])

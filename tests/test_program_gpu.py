@@ -72,15 +72,98 @@ def test_min_problem_redirect(engine, tmp_path, capsys):
     assert r["z"] == 0.0 and r["x"] == [0.0, 0.0]
 
 
+MODELS = {
+    "sample": None,  # tests/golden/TextFile.txt, the reference's data/TextFile.txt
+    "readme_ge_row": "max +2 +3 +4\n+1 +2 +3 <= 10\n+3 +2 +1 >= 15\n+ + +\n",
+    "fractions": "max +2.5 +3.125 +0.75 +4.0005\n+1.5 +2.25 +3.3 +0.7 <= 10.45\n"
+                 "+0.3 +0.2 +1.7 +2.9 <= 7.0005\n+ + + +\n",
+    "unit_rows_bound_it": "max +1 +1\n+1 -1 <= 2\n+ +\n",  # unbounded without Program.cs:114-124
+}
+
+
+def _model_path(name, tmp_path):
+    if MODELS[name] is None:
+        return os.path.join(HERE, "golden", "TextFile.txt")
+    f = tmp_path / f"{name}.txt"
+    f.write_text(MODELS[name])
+    return str(f)
+
+
+@pytest.mark.parametrize("name", list(MODELS))
+def test_option1_result_file_byte_for_byte(engine, tmp_path, name):
+    """Row f2, option 1 (Program.cs:91-140): the whole data/output_results.txt -- header, canonical
+    form (CanonicalFormConverter.cs:55-93), every IterationSnapshot through
+    TableIterationFormater.Format / {v:F3} (:22-48), the final block with SolutionSummary's {v:F6},
+    Z* / x_i through NumFormat.N3 (OutputFileWrite.cs:16-78) -- against the file assembled by the
+    INDEPENDENT restatement tests/ref_py_text.py (its own primal loop, its own number formatting;
+    nothing of the product is used to build the expected bytes).  Timestamp masked.  The reference
+    commits no output file, so text parity stays unpinned by the reference itself."""
+    import lpr_381_group_v22_amd as pkg
+    from lpr_381_group_v22_amd.program import run_option
+    from ref_py import parse_model_text, program_option1_constraints
+    from ref_py_text import PyPrimalText, mask_timestamp, py_write_full_results
+    path = _model_path(name, tmp_path)
+    p = pkg.InputFileParser()
+    p.ReadInputFile(path)
+    out = str(tmp_path / "data" / "output_results.txt")
+    run_option(p, "1", out, engine=engine)
+    got = open(out, "rb").read()
+    ptype, obj, cons, signs = parse_model_text(open(path).read())
+    cons1 = program_option1_constraints(len(obj), cons)  # Program.cs:114-124 (parser's own list)
+    ref = PyPrimalText(obj, cons1, True)
+    snaps, _console = ref.solve_text()
+    want = py_write_full_results("Primal Simplex Algorithm", ptype, obj, cons1, signs, snaps,
+                                 ref.FinalZ, ref.SolutionVector)
+    assert mask_timestamp(got) == want
+    if name == "sample":
+        assert len(snaps) == 8 and b"Iteration 6 - After pivot" in got
+    if name == "unit_rows_bound_it":
+        assert ref.status == "optimal" and b"Z* = 2\r\n" in got
+
+
+def test_option3_result_file_parts_that_do_not_need_the_narration(engine, tmp_path):
+    """Option 3 (Program.cs:356-415) writes ONE captured console text through WriteSnapshotsOnly
+    (OutputFileWrite.cs:83-119).  Compared byte for byte with the independent restatement: the
+    file's frame (header, "=== Solver Log ===", final results through N3) and the captured text up
+    to the end of the primal solve (banner, DisplayCanonicalForm, every Before / After pivot table,
+    the summary).  NOT mirrored and not compared: the Branch & Bound narration in between
+    (BranchBoundSimplexSolver.cs: 50 Console.Write sites incl. every intermediate tableau of every
+    child and .NET exception dumps) -- control-plane text, DESIGN.md section 9."""
+    import lpr_381_group_v22_amd as pkg
+    from lpr_381_group_v22_amd.program import run_option
+    from ref_py import parse_model_text, program_option1_constraints
+    from ref_py_text import (CRLF, PyPrimalText, mask_timestamp, py_canonical_form_console,
+                             py_write_snapshots_only)
+    path = os.path.join(HERE, "golden", "TextFile.txt")
+    p = pkg.InputFileParser()
+    p.ReadInputFile(path)
+    out = str(tmp_path / "output_results.txt")
+    r = run_option(p, "3", out, engine=engine)
+    got = mask_timestamp(open(out, "rb").read())
+    ptype, obj, cons, signs = parse_model_text(open(path).read())
+    ref = PyPrimalText(obj, program_option1_constraints(len(obj), cons), True)
+    _snaps, console = ref.solve_text()
+    head = ("Solving with Branch and Bound Simplex Algorithm..." + CRLF
+            + py_canonical_form_console(ptype, obj, cons, signs) + console)
+    tail = ("\n=== Branch & Bound Result ===" + CRLF + "Z* = 15" + CRLF  # Program.cs:391-394
+            + "".join(f"x{i + 1} = {v}" + CRLF for i, v in enumerate([0, 1, 1, 1, 0, 1])))
+    frame = py_write_snapshots_only("Branch and Bound Simplex Algorithm", [head + "<NARRATION>" + tail],
+                                    r["z"], r["x"])
+    pre, post = frame.split(b"<NARRATION>")
+    assert got.startswith(pre), "frame / canonical form / primal console text differ"
+    assert got.endswith(post), "result block / final results differ"
+
+
 def test_option2_result_file_byte_for_byte(engine, tmp_path):
     """The whole data/output_results.txt of option 2 on the reference's sample model against the
-    file written from the independent restatement (tests/ref_py.py: PyRevised captures +
-    CaptureSnapshot's text + NumFormat.N3), timestamp line masked.  The reference commits no output
+    bytes assembled by the independent restatement (tests/ref_py.py: PyRevised captures +
+    CaptureSnapshot's text + NumFormat.N3; tests/ref_py_text.py: WriteFullResults + the canonical
+    form -- nothing of the product builds the expected file), timestamp line masked.  The reference commits no output
     file (data/output_results.txt is empty), so this pins the device path and the host mirror
     against the second restatement, not against the C# itself: text parity unpinned."""
     import re
     import lpr_381_group_v22_amd as pkg
-    from lpr_381_group_v22_amd.program import run_option, write_full_results
+    from lpr_381_group_v22_amd.program import run_option
     from ref_py import (PyRevised, parse_model_text, program_option2_constraints,
                         py_snapshot_text)
     import lp_cases
@@ -93,11 +176,32 @@ def test_option2_result_file_byte_for_byte(engine, tmp_path):
     ref = PyRevised(obj, cons2, ptype == "min")
     assert ref.solve(capture=True) == "optimal"
     snaps = [py_snapshot_text(s, ref.n, ref.m, ptype == "min") for s in ref.snapshots]
-    want_path = str(tmp_path / "want.txt")
-    write_full_results(want_path, "Revised Primal Simplex Algorithm (T-*)", ptype, obj,
-                       [pkg.Constraint(list(c.Coefficients), c.Relation, c.RHS) for c in cons2],
-                       signs, snaps, ref.FinalZ, ref.SolutionVector)
-    want = open(want_path, "rb").read()
-    mask = re.compile(rb"Timestamp: [^\r\n]*")
+    from ref_py_text import py_write_full_results
+    want = py_write_full_results("Revised Primal Simplex Algorithm (T-*)", ptype, obj, cons2, signs,
+                                 snaps, ref.FinalZ, ref.SolutionVector)
+    from ref_py_text import mask_timestamp
     assert len(ref.snapshots) == 7 and b"--- Iteration 7 ---" in got
-    assert mask.sub(b"Timestamp:", got) == mask.sub(b"Timestamp:", want)
+    assert mask_timestamp(got) == want
+
+
+def test_unbounded_snapshots_and_console_text(engine, capsys):
+    """PrimalSimplexSolver.Solve's unbounded exit (:129-135): "Unbounded Solution!", FinalTableau
+    kept, an "Unbounded Tableau" snapshot -- IterationSnapshots and the console text of the mirror
+    class against the independent restatement (tests/ref_py_text.py)."""
+    import lpr_381_group_v22_amd as pkg
+    from ref_py import PyConstraint
+    from ref_py_text import CRLF, PyPrimalText
+    obj = [1.0, 2.0, 0.5]
+    cons = [([1.0, -1.0, 0.25], "<=", 2.0), ([-2.0, 0.0, 1.0], "<=", 3.5)]
+    ref = PyPrimalText(obj, [PyConstraint(list(a), r, b) for a, r, b in cons], True)
+    snaps, console = ref.solve_text()
+    assert ref.status == "unbounded" and "Unbounded Tableau" in snaps[-1]
+    s = pkg.PrimalSimplexSolver(obj, [pkg.Constraint(list(a), r, b) for a, r, b in cons], True,
+                                engine=engine, verbose=True, snapshots="all")
+    capsys.readouterr()
+    s.Solve()
+    out = capsys.readouterr().out
+    assert s.IterationSnapshots == snaps
+    assert s.SolutionVector is None and s.FinalZ == 0.0 and s.FinalTableau is not None
+    # print() terminates lines with "\n" where Console.WriteLine writes Environment.NewLine
+    assert out.replace(CRLF, "\n") == console.replace(CRLF, "\n")
