@@ -39,6 +39,7 @@ __device__ __forceinline__ int eps_fold(int lo, int hi, double best, F val, int*
     const int tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & (kWave - 1), wave = tid / kWave, nw = nt / kWave;
     const int n = hi - lo;
+    if (n <= 0) return -1;  // (uniform over the block)
     const int c = (n + nt - 1) / nt;  // candidates per thread, contiguous
     const bool cached = c <= K;
     const int base = lo + tid * c;
@@ -46,11 +47,20 @@ __device__ __forceinline__ int eps_fold(int lo, int hi, double best, F val, int*
     unsigned flags = 0;  // bit k: candidate base + k can still be taken
     __syncthreads();     // lds_i / lds_v may still be read by a previous fold
     if (cached) {
-        double lmin = INFINITY;
+        // all K values are requested before the first is looked at: val() runs on an index that is
+        // always valid (a lane's unused slots re-read `lo`), so its loads carry no branch and go
+        // out back to back -- one memory round trip per thread instead of one per candidate
+        // (measured in the revised entering fold: 24 us -> a few)
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const int idx = base + k;
-            v[k] = (k < c && idx < hi) ? val(idx) : NAN;
+            const bool ok = k < c && idx < hi;
+            const double x = val(ok ? idx : lo);
+            v[k] = ok ? x : (double)NAN;
+        }
+        double lmin = INFINITY;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
             if (v[k] < lmin) {  // strict prefix minimum within the chunk
                 flags |= 1u << k;
                 lmin = v[k];

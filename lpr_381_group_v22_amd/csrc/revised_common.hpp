@@ -14,6 +14,10 @@ struct RevState {
     int64_t iter;         // completed pivots
     int64_t max_iter;     // stop when iter reaches this (<= 0: none)
     int64_t log_cap;      // capacity of the (row, enter, leave) log in triples
+    // arrival counters of the fused kernels (revised_fused.hip): the workgroup whose add comes
+    // last runs the selection on what the others have stored, then puts the counter back to 0
+    int32_t arrive_rc;    // k_rev_rc_enter
+    int32_t arrive_xu;    // k_rev_xu_ratio
 };
 
 }  // namespace lpr
@@ -26,6 +30,8 @@ struct lpr_revised {
     int lda = 0, ldb = 0;       // leading dimensions of A (m x n) and B^-1 (m x m), 16-double padded
     int is_min = 0;
     double* A = nullptr;        // m x lda
+    double* At = nullptr;       // n x ldb: A transposed (column j of A contiguous: GetColumn(A, j) :390-396
+                                // is ONE 8 m-byte read instead of m DRAM pages; 8 m n more bytes of HBM)
     double* Binv = nullptr;     // m x ldb
     double* b = nullptr;        // m
     double* c = nullptr;        // n   (= -cOrig for min, :51)
@@ -53,6 +59,7 @@ struct lpr_revised {
     int32_t* snap_basis = nullptr;   // m   basisForRatios_Pre (:186)
     double* snap_scal = nullptr;     // [0] enteringRC_pre (:189-191), [1] zWorking = Dot(cB, xB)
     double* h_snap_scal = nullptr;   // pinned, 4 doubles: + [2] zOriginal
+    unsigned long long* dbg_stamps = nullptr;  // LPR_REV_STAMPS=1 (diagnostic), 8 words
     int64_t total_iter = 0;
     int last_status = 0;
 };

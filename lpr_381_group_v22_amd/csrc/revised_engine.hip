@@ -4,6 +4,7 @@
 #include "engine_common.hpp"
 #include "revised_common.hpp"
 
+#include <cstdlib>
 #include <new>
 
 #pragma clang fp contract(off)
@@ -12,27 +13,33 @@ namespace lpr {
 
 // revised_kernels.hip
 void rev_launch_iteration(lpr_revised* s, bool snapshot);
+void rev_launch_iteration_batched(lpr_revised* s);
+void rev_launch_y(lpr_revised* s);
 void rev_launch_prices(lpr_revised* s);
 void rev_launch_zworking(lpr_revised* s);
 void rev_launch_matmul_exact(lpr_revised* s, double* Cout, int ldc);
 void rev_launch_extract(lpr_revised* s);
 void rev_launch_init(lpr_revised* s);
 void rev_launch_synthetic(lpr_revised* s, uint64_t seed);
+void rev_launch_transpose_a(lpr_revised* s);
 void rev_launch_gemm(lpr_revised* s, double* Cout, int ldc);
 
 static void rev_release_device(lpr_revised* s) {
     hipSetDevice(s->eng->device);
     if (s->eng->stream) hipStreamSynchronize(s->eng->stream);
-    hipFree(s->A); hipFree(s->Binv); hipFree(s->b); hipFree(s->c); hipFree(s->cOrig);
+    hipFree(s->A); hipFree(s->At); hipFree(s->Binv); hipFree(s->b); hipFree(s->c); hipFree(s->cOrig);
     hipFree(s->cB); hipFree(s->xB); hipFree(s->y); hipFree(s->rcx); hipFree(s->acol);
     hipFree(s->u); hipFree(s->fac); hipFree(s->browbuf); hipFree(s->x); hipFree(s->z);
     hipFree(s->basic); hipFree(s->is_basic); hipFree(s->log); hipFree(s->state);
     hipFree(s->gemm_out);
+    hipFree(s->dbg_stamps);
+    s->dbg_stamps = nullptr;
     hipFree(s->snap_ratios); hipFree(s->snap_basis); hipFree(s->snap_scal);
     if (s->h_snap_scal) hipHostFree(s->h_snap_scal);
     s->snap_ratios = s->snap_scal = s->h_snap_scal = nullptr;
     s->snap_basis = nullptr;
     if (s->h_state) hipHostFree(s->h_state);
+    s->At = nullptr;
     s->A = s->Binv = s->b = s->c = s->cOrig = s->cB = s->xB = s->y = s->rcx = s->acol = nullptr;
     s->u = s->fac = s->browbuf = s->x = s->z = s->gemm_out = nullptr;
     s->basic = s->log = nullptr;
@@ -66,6 +73,7 @@ static int rev_alloc(lpr_engine* e, int n, int m, int is_min, lpr_revised** out)
     auto chk = [&](hipError_t x) { if (err == hipSuccess) err = x; };
     const size_t D = sizeof(double);
     chk(hipMalloc(&s->A, (size_t)m * s->lda * D));
+    chk(hipMalloc(&s->At, (size_t)n * s->ldb * D));
     chk(hipMalloc(&s->Binv, (size_t)m * s->ldb * D));
     chk(hipMalloc(&s->b, (size_t)s->ldb * D));
     chk(hipMalloc(&s->c, (size_t)s->lda * D));
@@ -160,6 +168,10 @@ int lpr_revised_create(lpr_engine* e, int n, int m, const double* objective, con
     chk(hipMemcpyAsync(s->cOrig, objective, (size_t)n * sizeof(double), hipMemcpyHostToDevice,
                        st));
     chk(hipMemcpyAsync(s->c, cc.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+    if (err == hipSuccess) {
+        rev_launch_transpose_a(s);
+        chk(hipGetLastError());
+    }
     chk(hipStreamSynchronize(st));  // inputs (and cc) are borrowed for this call only
     if (err != hipSuccess) {
         set_error("lpr_revised_create: %s", hipGetErrorString(err));
@@ -175,6 +187,7 @@ int lpr_revised_synthetic(lpr_engine* e, int m, int n, uint64_t seed, lpr_revise
     int rc = rev_alloc(e, n, m, 0, &s);
     if (rc != LPR_OK_OPTIMAL) return rc;
     rev_launch_synthetic(s, seed);
+    rev_launch_transpose_a(s);
     hipError_t err = hipGetLastError();
     if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
     if (err != hipSuccess) {
@@ -226,6 +239,12 @@ int lpr_revised_solve(lpr_revised* s, const lpr_solve_opts* opts, lpr_revised_re
     hs->log_cap = s->log_cap;
     LPR_HIP(hipMemcpyAsync(s->state, hs, sizeof(RevState), hipMemcpyHostToDevice, st));
 
+    const char* sv = std::getenv("LPR_REV_STAMPS");
+    const bool stamps = sv && sv[0] == '1';
+    if (stamps && !s->dbg_stamps) LPR_HIP(hipMalloc(&s->dbg_stamps, 16 * sizeof(unsigned long long)));
+    // y = c_B B^-1 of the state the call starts from; every pivot's update pass then leaves the
+    // next iteration's y behind (same sums, same order: RevisedPrimalSimplexSolver.cs:93 = :219)
+    rev_launch_y(s);
     int status = kRunning;
     int64_t iter = start;
     while (status == kRunning) {
@@ -236,7 +255,30 @@ int lpr_revised_solve(lpr_revised* s, const lpr_solve_opts* opts, lpr_revised_re
             LPR_HIP(hipMemcpyAsync(&s->state->log_cap, &hs->log_cap, sizeof(int64_t),
                                    hipMemcpyHostToDevice, st));
         }
-        for (int k = 0; k < batch; ++k) rev_launch_iteration(s, false);
+        for (int k = 0; k < batch; ++k) {
+            if (stamps && k == batch - 1) {  // the last iteration of a batch is the one stamped
+                unsigned long long init[16] = {~0ull, 0, 0, 0, ~0ull, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                LPR_HIP(hipMemcpyAsync(s->dbg_stamps, init, sizeof init, hipMemcpyHostToDevice, st));
+                LPR_HIP(hipStreamSynchronize(st));
+            }
+            rev_launch_iteration_batched(s);
+        }
+        if (stamps) {
+            unsigned long long t[16];
+            LPR_HIP(hipStreamSynchronize(st));
+            LPR_HIP(hipMemcpy(t, s->dbg_stamps, sizeof t, hipMemcpyDeviceToHost));
+            std::fprintf(stderr, "rev stamps (us): rc walk %.2f, to tail %.2f, enter tail %.2f | xu walk "
+                         "%.2f, to tail %.2f, ratio tail %.2f | rc start -> xu start %.2f | enter: fold "
+                         "%.2f gather %.2f | ratio: loads+exits %.2f replay %.2f rest %.2f\n",
+                         (t[1] - t[0]) * 0.01, (double)((long long)(t[2] - t[1])) * 0.01,
+                         (t[3] - t[2]) * 0.01, (t[5] - t[4]) * 0.01,
+                         (double)((long long)(t[6] - t[5])) * 0.01, (t[7] - t[6]) * 0.01,
+                         (t[4] - t[0]) * 0.01, (double)((long long)(t[8] - t[2])) * 0.01,
+                         (double)((long long)(t[3] - t[8])) * 0.01,
+                         (double)((long long)(t[9] - t[6])) * 0.01,
+                         (double)((long long)(t[10] - t[9])) * 0.01,
+                         (double)((long long)(t[7] - t[10])) * 0.01);
+        }
         LPR_HIP(hipGetLastError());
         LPR_HIP(hipMemcpyAsync(hs, s->state, sizeof(RevState), hipMemcpyDeviceToHost, st));
         LPR_HIP(hipStreamSynchronize(st));

@@ -53,6 +53,9 @@ __device__ __forceinline__ double ring_walk(const double* __restrict__ row, int 
         double2 a[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) a[u] = r2[u];
+        // the first group is requested in full before the pattern below starts: that is the
+        // distance (8 reads = 16 adds) every later read keeps ahead of its use
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int k0 = 0; k0 < RC; k0 += 16) {
             double2 na[8];
@@ -199,6 +202,271 @@ __global__ __launch_bounds__(64 * (NSW + 1)) void k_rev_update_y(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// "Last workgroup done": every workgroup stores its outputs with agent-scope (sc1, write-through)
+// stores, waits for them (s_waitcnt vmcnt(0)) and adds 1 to a counter in the control block; the
+// workgroup whose add returns nwg - 1 knows every other workgroup's stores have landed and reads
+// them with agent-scope loads (MI355X_MICROARCH.md, hand-off table, first row).  Called by ONE
+// lane after that wave's wait; the result goes through LDS to the rest of the workgroup.
+__device__ __forceinline__ bool arrive_is_last(int32_t* ctr, int nwg) {
+    const int old = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return old == nwg - 1;
+}
+__device__ __forceinline__ void st_sc1(double* p, double v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+typedef double rv2d_t __attribute__((ext_vector_type(2)));
+
+// Diagnostic stamps (LPR_REV_STAMPS=1: lpr_revised_solve prints them; nullptr otherwise).  Four
+// 64-bit words per kernel: min entry, max end-of-walk, tail start, tail end (100 MHz ticks).
+__device__ __forceinline__ void stamp_min(unsigned long long* d, int k) {
+    if (d) atomicMin(d + k, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+}
+__device__ __forceinline__ void stamp_max(unsigned long long* d, int k) {
+    if (d) atomicMax(d + k, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_rev_rc_enter.  rc_j = c_j - sum_{i asc} y_i * A[i, j] (:96-98: Dot(y, GetColumn(A, j)), s starts
+// at +0.0), 32 columns (256 bytes per row) per workgroup, all m rows in order through the ring;
+// then, in the workgroup that arrives last, the entering fold and GetColumn (rev_enter_body).
+//   stagers (NSW waves): a wave-instruction covers 4 rows x 16 double2; a lane holds NQ double2 of
+//     one column pair per chunk (RC = NSW * 4 * NQ), loads run TWO chunks ahead of the ring fill
+//     (A comes from HBM: 268 MB, non-temporal so that it does not evict B^-1 from the Infinity
+//     Cache); the product y_i * A[i, j] is rounded as the C# rounds it (:446) before the add.
+//   walker (wave 0, lanes 0..31): the 32 chains.
+// Algorithmic bytes: 8 * m * n.
+template <int NSW, int NQ>
+__global__ __launch_bounds__(64 * (NSW + 1)) void k_rev_rc_enter(
+    const double* __restrict__ A, int lda, int m, int n, const double* __restrict__ y,
+    const double* __restrict__ c, double* __restrict__ rcx, const uint8_t* __restrict__ is_basic,
+    const double* __restrict__ Binv, int ldb, double* __restrict__ acol, double* __restrict__ u,
+    RevState* st, unsigned long long* dbg, const double* __restrict__ At) {
+    constexpr int RC = NSW * 4 * NQ;
+    constexpr int ROW = RC + kRingPad;
+    constexpr int S = 4;
+    static_assert(RC % 32 == 0, "bank spreading assumes RC % 32 == 0");
+    extern __shared__ __attribute__((aligned(16))) double rev_ring[];  // [S][32][ROW]
+    __shared__ RingCtl ctl;
+    __shared__ int s_last;
+    if (st->status != kRunning) return;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    if (tid < 4) ctl.ready[tid] = 0;
+    if (tid == 4) ctl.done = 0;
+    if (tid == 5) s_last = 0;
+    __syncthreads();
+    const int j0 = blockIdx.x * 32;
+    const int nchunk = (m + RC - 1) / RC;
+
+    if (wave == 0) {
+        __builtin_amdgcn_s_setprio(3);
+        if (lane == 0) stamp_min(dbg, 0);
+        double s = 0.0;
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const int slot = ch % S;
+            const int need = NSW * (ch / S + 1);
+            while (lds_load(&ctl.ready[slot]) < need) __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+            if (lane < 32)
+                s = ring_walk<RC>(rev_ring + ((size_t)slot * 32 + lane) * ROW, min(RC, m - ch * RC), s);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) __atomic_store_n(&ctl.done, ch + 1, __ATOMIC_RELAXED);
+        }
+        if (lane < 32 && j0 + lane < n) st_sc1(rcx + j0 + lane, c[j0 + lane] - s);  // :97
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) stamp_max(dbg, 1);
+        if (lane == 0 && arrive_is_last(&st->arrive_rc, (int)gridDim.x)) s_last = 1;
+    } else {
+        const int w = wave - 1;
+        const int cp = lane & 15;   // column pair of the strip
+        const int rs = lane >> 4;   // row of a wave-instruction
+        const int col = j0 + 2 * cp;
+        const bool col_ok = col < lda;
+        rv2d_t xb[3][NQ];
+        double yb[3][NQ];
+        auto load_chunk = [&](int ch, rv2d_t (&xx)[NQ], double (&yy)[NQ]) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int i = ch * RC + (q * NSW + w) * 4 + rs;
+                const bool ok = i < m && col_ok && ch < nchunk;
+                xx[q] = ok ? __builtin_nontemporal_load(
+                                 reinterpret_cast<const rv2d_t*>(A + (size_t)i * lda + col))
+                           : (rv2d_t){0.0, 0.0};
+                yy[q] = ok ? y[i] : 0.0;
+            }
+        };
+        auto fill = [&](int ch, const rv2d_t (&xx)[NQ], const double (&yy)[NQ]) {
+            const int slot = ch % S;
+            while (lds_load(&ctl.done) < ch - S + 1) __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+            double* __restrict__ tile = rev_ring + (size_t)slot * 32 * ROW;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int rr = (q * NSW + w) * 4 + rs;
+                tile[(2 * cp) * ROW + rr] = yy[q] * xx[q].x;      // y[i] * col[i], rounded (:446)
+                tile[(2 * cp + 1) * ROW + rr] = yy[q] * xx[q].y;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add(&ctl.ready[slot], 1, __ATOMIC_RELAXED,
+                                                  __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+        load_chunk(0, xb[0], yb[0]);
+        load_chunk(1, xb[1], yb[1]);
+        for (int ch = 0; ch < nchunk; ch += 3) {   // register sets rotate with the chunk number
+            load_chunk(ch + 2, xb[2], yb[2]);
+            fill(ch, xb[0], yb[0]);
+            if (ch + 1 < nchunk) {
+                load_chunk(ch + 3, xb[0], yb[0]);
+                fill(ch + 1, xb[1], yb[1]);
+            }
+            if (ch + 2 < nchunk) {
+                load_chunk(ch + 4, xb[1], yb[1]);
+                fill(ch + 2, xb[2], yb[2]);
+            }
+        }
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // ---- the entering variable (:105-121) and its column (:149-151), by the last workgroup ----
+    __threadfence_block();
+    if (tid == 0) stamp_max(dbg, 2);
+    rev_enter_body<true, 32>(rcx, y, is_basic, n, m, st, At, ldb, Binv, ldb, acol, u, dbg, rev_ring,
+                             S * 32 * ROW);
+    if (tid == 0) st->arrive_rc = 0;
+    __syncthreads();
+    if (tid == 0) stamp_max(dbg, 3);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_rev_xu_ratio.  x_B = B^-1 b (:89) and, when the entering variable is structural, u = B^-1 a_e
+// (:150) -- MultiplyMatrixVector :398-410, r_i = sum_{j asc} M[i, j] * v[j], s from +0.0 -- in ONE
+// pass over B^-1: 16 rows per workgroup, lanes 0..15 of the walker chain the rows against b,
+// lanes 16..31 the same rows against a_e.  Then, in the workgroup that arrives last, the loop
+// head's exits, the ratio fold, the bookkeeping and the eta column (rev_ratio_body).
+//   stagers (8 waves): a wave-instruction is one row's 128 columns of the chunk (1 KB contiguous);
+//     wave w stages rows 2w, 2w + 1; loads run two chunks ahead of the ring fill.
+// Algorithmic bytes: 8 * m^2.
+constexpr int kXuRC = 128;
+constexpr int kXuNSW = 8;
+__global__ __launch_bounds__(64 * (kXuNSW + 1)) void k_rev_xu_ratio(
+    const double* __restrict__ Binv, int ld, int m, int n, const double* __restrict__ b,
+    double* __restrict__ xB, const double* __restrict__ acol, double* __restrict__ u,
+    int32_t* __restrict__ basic, uint8_t* __restrict__ is_basic, double* __restrict__ cB,
+    const double* __restrict__ c, double* __restrict__ browbuf, double* __restrict__ fac,
+    int32_t* __restrict__ log, RevState* st, unsigned long long* dbg) {
+    constexpr int RC = kXuRC, NSW = kXuNSW;
+    constexpr int ROW = RC + kRingPad;
+    constexpr int S = 4;
+    extern __shared__ __attribute__((aligned(16))) double rev_ring[];  // [S][32][ROW]
+    __shared__ RingCtl ctl;
+    __shared__ int s_last;
+    if (st->status != kRunning) return;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    if (tid < 4) ctl.ready[tid] = 0;
+    if (tid == 4) ctl.done = 0;
+    if (tid == 5) s_last = 0;
+    __syncthreads();
+    const int e = st->entering;
+    const bool two = e >= 0 && e < n;   // slack: u = BInverse[:, k], written by the entering tail
+    const int row0 = blockIdx.x * 16;
+    const int nchunk = (m + RC - 1) / RC;
+
+    if (wave == 0) {
+        __builtin_amdgcn_s_setprio(3);
+        if (lane == 0) stamp_min(dbg, 4);
+        double s = 0.0;
+        const bool mine = lane < 16 || (two && lane < 32);
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const int slot = ch % S;
+            const int need = NSW * (ch / S + 1);
+            while (lds_load(&ctl.ready[slot]) < need) __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+            if (mine)
+                s = ring_walk<RC>(rev_ring + ((size_t)slot * 32 + lane) * ROW, min(RC, m - ch * RC), s);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) __atomic_store_n(&ctl.done, ch + 1, __ATOMIC_RELAXED);
+        }
+        if (lane < 16 && row0 + lane < m) st_sc1(xB + row0 + lane, s);
+        if (two && lane >= 16 && lane < 32 && row0 + lane - 16 < m) st_sc1(u + row0 + lane - 16, s);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) stamp_max(dbg, 5);
+        if (lane == 0 && arrive_is_last(&st->arrive_xu, (int)gridDim.x)) s_last = 1;
+    } else {
+        const int w = wave - 1;
+        struct Regs {
+            double2 r0, r1;   // rows 2w, 2w + 1: columns k0 + 2 lane, + 1
+            double2 bv, av;
+        };
+        constexpr int D = 4;   // chunks the loads run ahead of the ring fill (D + 1 register sets)
+        Regs rg[D + 1];
+        const int ld2 = ld >> 1;
+        const double2* __restrict__ B2 = reinterpret_cast<const double2*>(Binv);
+        const int ia = row0 + 2 * w, ib = ia + 1;
+        auto load_chunk = [&](int ch, Regs& g) {
+            const int k = ch * RC + 2 * lane;   // first of this lane's two columns
+            const bool ok = ch < nchunk && k < ld;
+            const double2 z = make_double2(0.0, 0.0);
+            g.r0 = (ok && ia < m) ? B2[(size_t)ia * ld2 + (k >> 1)] : z;
+            g.r1 = (ok && ib < m) ? B2[(size_t)ib * ld2 + (k >> 1)] : z;
+            g.bv.x = (ok && k < m) ? b[k] : 0.0;
+            g.bv.y = (ok && k + 1 < m) ? b[k + 1] : 0.0;
+            g.av = z;
+            if (two) {
+                g.av.x = (ok && k < m) ? acol[k] : 0.0;
+                g.av.y = (ok && k + 1 < m) ? acol[k + 1] : 0.0;
+            }
+        };
+        auto fill = [&](int ch, const Regs& g) {
+            const int slot = ch % S;
+            while (lds_load(&ctl.done) < ch - S + 1) __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+            double* __restrict__ tile = rev_ring + (size_t)slot * 32 * ROW;
+            // M[i, j] * v[j], rounded as the C# rounds it before the add (:406)
+            double2 p;
+            p.x = g.r0.x * g.bv.x; p.y = g.r0.y * g.bv.y;
+            *reinterpret_cast<double2*>(tile + (2 * w) * ROW + 2 * lane) = p;
+            p.x = g.r1.x * g.bv.x; p.y = g.r1.y * g.bv.y;
+            *reinterpret_cast<double2*>(tile + (2 * w + 1) * ROW + 2 * lane) = p;
+            if (two) {
+                p.x = g.r0.x * g.av.x; p.y = g.r0.y * g.av.y;
+                *reinterpret_cast<double2*>(tile + (16 + 2 * w) * ROW + 2 * lane) = p;
+                p.x = g.r1.x * g.av.x; p.y = g.r1.y * g.av.y;
+                *reinterpret_cast<double2*>(tile + (16 + 2 * w + 1) * ROW + 2 * lane) = p;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add(&ctl.ready[slot], 1, __ATOMIC_RELAXED,
+                                                  __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+#pragma unroll
+        for (int k = 0; k < D; ++k) load_chunk(k, rg[k]);
+        for (int ch = 0; ch < nchunk; ch += D + 1) {  // register sets rotate with the chunk number
+#pragma unroll
+            for (int k = 0; k <= D; ++k) {
+                if (ch + k < nchunk) {
+                    load_chunk(ch + k + D, rg[(k + D) % (D + 1)]);
+                    fill(ch + k, rg[k]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // ---- exits of the loop head, ratio test, bookkeeping, eta column: the last workgroup ----
+    __threadfence_block();
+    if (tid == 0) stamp_max(dbg, 6);
+    double* s_rat = rev_ring;                                       // kRatioLds doubles
+    int* s_bvi = reinterpret_cast<int*>(rev_ring + kRatioLds);      // kRatioLds ints
+    double* s_u = rev_ring + kRatioLds + kRatioLds / 2;             // kRatioLds doubles
+    rev_ratio_body<true>(u, xB, basic, is_basic, cB, c, Binv, ld, browbuf, fac, log, n, m, st, s_rat,
+                         s_bvi, s_u, dbg);
+    __syncthreads();
+    if (tid == 0) st->arrive_xu = 0;
+    if (tid == 0) stamp_max(dbg, 7);
+}
+
 template <int NSW, int NQ>
 static void launch_update_y(lpr_revised* s, int do_update) {
     constexpr int RC = NSW * 8 * NQ;
@@ -214,6 +482,40 @@ static void launch_update_y(lpr_revised* s, int do_update) {
     hipLaunchKernelGGL((k_rev_update_y<NSW, NQ>), dim3((s->m + 15) / 16), dim3(64 * (NSW + 1)), lds,
                        s->eng->stream, s->Binv, s->ldb, s->m, s->browbuf, s->fac, s->cB, s->y,
                        s->state, do_update);
+}
+
+template <class K>
+static void raise_dyn_lds(K kernel, size_t bytes, unsigned long long& asked) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !(asked & (1ull << dev))) {
+        asked |= 1ull << dev;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    }
+}
+
+// rc = c - y A, then the entering variable and its column
+void rev_launch_rc_enter(lpr_revised* s) {
+    constexpr int NSW = 6, NQ = 4;
+    constexpr size_t lds = (size_t)4 * 32 * (NSW * 4 * NQ + kRingPad) * sizeof(double);
+    static unsigned long long asked = 0;
+    raise_dyn_lds(&k_rev_rc_enter<NSW, NQ>, lds, asked);
+    hipLaunchKernelGGL((k_rev_rc_enter<NSW, NQ>), dim3((s->n + 31) / 32), dim3(64 * (NSW + 1)), lds,
+                       s->eng->stream, s->A, s->lda, s->m, s->n, s->y, s->c, s->rcx, s->is_basic,
+                       s->Binv, s->ldb, s->acol, s->u, s->state, s->dbg_stamps, s->At);
+}
+
+// x_B and u in one pass over B^-1, then the ratio test and the bookkeeping of the pivot
+void rev_launch_xu_ratio(lpr_revised* s) {
+    constexpr size_t lds = (size_t)4 * 32 * (kXuRC + kRingPad) * sizeof(double);
+    static_assert(lds >= kRatioLds * (2 * sizeof(double) + sizeof(int)), "the tail borrows the ring");
+    static unsigned long long asked = 0;
+    raise_dyn_lds(&k_rev_xu_ratio, lds, asked);
+    hipLaunchKernelGGL(k_rev_xu_ratio, dim3((s->m + 15) / 16), dim3(64 * (kXuNSW + 1)), lds,
+                       s->eng->stream, s->Binv, s->ldb, s->m, s->n, s->b, s->xB, s->acol, s->u,
+                       s->basic, s->is_basic, s->cB, s->c, s->browbuf, s->fac, s->log, s->state,
+                       s->dbg_stamps);
 }
 
 // y = c_B B^-1 of the current state (the head of a call: nothing to apply)

@@ -18,12 +18,13 @@
 #include "engine_common.hpp"
 #include "revised_common.hpp"
 #include "fold_common.hpp"
+#include "revised_select.hpp"
 
 #pragma clang fp contract(off)
 
 namespace lpr {
 
-constexpr double kEps = 1e-9;  // RevisedPrimalSimplexSolver.cs:12
+constexpr double kEps = kRevEps;  // RevisedPrimalSimplexSolver.cs:12
 
 // ------------------------------------------------------------------------------------------
 // out[i] = sum_{j asc} M[i, j] * v[j], s starts at +0.0  (MultiplyMatrixVector :398-410).
@@ -196,9 +197,21 @@ __global__ __launch_bounds__(256) void k_rev_colsum(const double* __restrict__ M
             const int idx = sid + q * NS;
             const int r = idx / H, cc = (idx % H) * 2;
             const int gi = i0 + r;
-            rm[q] = (idx < RC * H && gi < rows && j0 + cc < ld)
-                        ? *reinterpret_cast<const double2*>(M + (size_t)gi * ld + j0 + cc)
-                        : make_double2(0.0, 0.0);
+            // A (CB = 32) is read once per iteration and is larger than the Infinity Cache: its
+            // stream is marked non-temporal so that it does not push B^-1 (134 MB, read by the two
+            // passes either side of this one) out of the cache
+            typedef double v2d_t __attribute__((ext_vector_type(2)));
+            const double* gp = M + (size_t)gi * ld + j0 + cc;
+            if (idx < RC * H && gi < rows && j0 + cc < ld) {
+                if (CB == 32) {
+                    const v2d_t t = __builtin_nontemporal_load(reinterpret_cast<const v2d_t*>(gp));
+                    rm[q] = make_double2(t.x, t.y);
+                } else {
+                    rm[q] = *reinterpret_cast<const double2*>(gp);
+                }
+            } else {
+                rm[q] = make_double2(0.0, 0.0);
+            }
             rv[q] = (idx < RC * H && gi < rows) ? v[gi] : 0.0;
         }
     };
@@ -258,30 +271,7 @@ __global__ __launch_bounds__(256) void k_rev_colsum(const double* __restrict__ M
 }
 
 // ------------------------------------------------------------------------------------------
-// Block-wide minimum of an int (smallest index that satisfies a predicate; INT_MAX = none).
-__device__ __forceinline__ int block_min_int(int v, int* lds) {
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = threadIdx.x / kWave;
-    const int nwaves = blockDim.x / kWave;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, kWave));
-    __syncthreads();
-    if (lane == 0) lds[wave] = v;
-    __syncthreads();
-    int r = lds[0];
-    for (int w = 1; w < nwaves; ++w) r = min(r, lds[w]);
-    return r;
-}
-
-// ------------------------------------------------------------------------------------------
-// Entering variable, RevisedPrimalSimplexSolver.cs:105-121:
-//     foreach vIdx in nonBasic ascending:  rc > EPS  and
-//         (none yet  or  rc > best + EPS  or  (|rc - best| <= EPS and vIdx < enteringIdx))  -> take
-// The third clause can never fire while indices are visited in ascending order.  The comparator is
-// an EPS-band rule and not associative, so it is not reduced as a tree: the fold is replayed
-// exactly by repeatedly searching, in parallel, for the FIRST index after the current one at
-// which the C# would replace its running best ("next take"), until there is none.  The number of
-// rounds is the number of replacements the sequential loop makes (O(log N) on random data).
+// The two selections (revised_select.hpp) as launches of their own: lpr_revised_step's path.
 __global__ __launch_bounds__(1024) void k_rev_enter(const double* __restrict__ rcx,
                                                     const double* __restrict__ y,
                                                     const uint8_t* __restrict__ is_basic, int n,
@@ -291,44 +281,9 @@ __global__ __launch_bounds__(1024) void k_rev_enter(const double* __restrict__ r
                                                     double* __restrict__ acol,
                                                     double* __restrict__ u) {
     if (st->status != kRunning) return;
-    const int tid = threadIdx.x;
-    // (the feasibility test of :90-91, "optimal" and the pivot limit are decided in k_rev_ratio,
-    // once x_B -- computed together with u in one pass over B^-1 -- is there; the entering choice
-    // itself does not read x_B, and nothing is modified before those tests either way)
-    const int N = n + m;
-    // "rc > EPS, and first or rc > best + EPS" over ascending non-basic indices (:105-121; the
-    // equal-within-EPS clause needs a smaller index than the current one and can never fire in
-    // ascending order).  With v = -rc this is eps_fold's "v < best - EPS" from best = +inf:
-    // negation is exact, and fl(-b - EPS) = -fl(b + EPS).
-    __shared__ int lds_i2[32];
-    __shared__ double lds_v2[32];
-    const int cur = eps_fold<16>(
-        0, N, INFINITY,
-        [&](int k) {
-            if (is_basic[k]) return (double)NAN;
-            const double rc = (k < n) ? rcx[k] : -y[k - n];  // rcS_k = -y_k (:100-102)
-            return (rc > kEps) ? -rc : (double)NAN;
-        },
-        lds_i2, lds_v2);
-    if (tid == 0) st->entering = cur;
-    // GetColumn (:390-396) rides the tail of this launch (it was a kernel of its own: 4.7 us plus a
-    // launch gap): structural e -> acol = A[:, e] (input of u = B^-1 a_e); slack e = n + k ->
-    // u = BInverse[:, k] directly (:151).  No entering variable: k_rev_ratio reports the optimum.
-    if (cur < 0) return;
-    for (int i = tid; i < m; i += blockDim.x) {
-        if (cur < n) acol[i] = A[(size_t)i * lda + cur];
-        else u[i] = Binv[(size_t)i * ldb + (cur - n)];
-    }
+    rev_enter_body<false, 16>(rcx, y, is_basic, n, m, st, A, lda, Binv, ldb, acol, u);  // A = At here
 }
 
-// ------------------------------------------------------------------------------------------
-// Ratio test, RevisedPrimalSimplexSolver.cs:154-176:
-//     for i ascending, u_i > EPS, ratio = xB_i / u_i:
-//         ratio < best - EPS  or  (|ratio - best| <= EPS and (none yet or basic[i] < basic[row]))
-// `best` may move UP by up to EPS on a band take, so no prefix-minimum shortcut is valid; the
-// same exact "next take" replay as k_rev_enter is used.  Then the bookkeeping of :181-212 and the
-// column of the elementary matrix E (:266-272): fac[r] = 1/p, fac[i] = -u_i / p.  The old pivot
-// row of B^-1 is copied to browbuf because k_rev_update works in place.
 __global__ __launch_bounds__(1024) void k_rev_ratio(const double* __restrict__ u,
                                                     const double* __restrict__ xB,
                                                     int32_t* __restrict__ basic,
@@ -340,164 +295,11 @@ __global__ __launch_bounds__(1024) void k_rev_ratio(const double* __restrict__ u
                                                     double* __restrict__ fac,
                                                     int32_t* __restrict__ log, int n, int m,
                                                     RevState* st) {
-    __shared__ int lds[16];
-    __shared__ double lds_best;
-    if (st->status != kRunning) return;
-    const int tid = threadIdx.x;
-    const int nt = blockDim.x;
-    const int e = st->entering;
-    {   // the loop head's exits, in the C#'s order: infeasible basis (:90-91), optimal (:124-146),
-        // then (no C# counterpart) the caller's pivot limit
-        int bad = INT_MAX;
-        for (int i = tid; i < m; i += nt)
-            if (xB[i] < -kEps) { bad = i; break; }
-        bad = block_min_int(bad, lds);
-        int32_t out = kRunning;
-        if (bad != INT_MAX) out = LPR_INFEASIBLE_BASIS;
-        else if (e < 0) out = LPR_OK_OPTIMAL;
-        else if (st->max_iter > 0 && st->iter >= st->max_iter) out = LPR_PIVOT_LIMIT;
-        __syncthreads();  // every lane has read the state before lane 0 changes it
-        if (out != kRunning) {
-            if (tid == 0) st->status = out;
-            return;
-        }
-    }
-
-    // Ratios and basic-variable indices of this lane's rows are computed ONCE into registers
-    // (first kCacheR * 1024 rows; rows beyond are re-read): NaN marks "u_i <= EPS" (:161,:172-175).
-    constexpr int kCacheR = 8;
-    double rat[kCacheR];
-    int bvi[kCacheR];
-#pragma unroll
-    for (int q = 0; q < kCacheR; ++q) {
-        const int i = tid + q * nt;
-        rat[q] = NAN;
-        bvi[q] = 0;
-        if (i < m) {
-            const double ui = u[i];
-            if (ui > kEps) rat[q] = xB[i] / ui;
-            bvi[q] = basic[i];
-        }
-    }
-    const bool cached_all = m <= kCacheR * nt;
-    int row = -1;           // leavingRow
-    double best = DBL_MAX;  // bestRatio
-    int cur = -1;           // last index examined by the replayed loop
-    // Up to kRatioLds rows: the ratios go to LDS and ONE wave replays the C#'s loop as it is
-    // written, 64 rows at a time -- a ballot finds the first row after the last take that the loop
-    // would take next -- with no workgroup barrier per take (three barriers per take cost ~2 us
-    // x ~9 takes of the 23 us this kernel took at m = 4096).
-    constexpr int kRatioLds = 4096;
     __shared__ double s_rat[kRatioLds];
     __shared__ int s_bvi[kRatioLds];
-    __shared__ int s_row;
-    if (m <= kRatioLds) {
-#pragma unroll
-        for (int q = 0; q < kCacheR; ++q) {
-            const int i = tid + q * nt;
-            if (i < m) {
-                s_rat[i] = rat[q];
-                s_bvi[i] = bvi[q];
-            }
-        }
-        __syncthreads();
-        if (tid < kWave) {
-            int brow = 0;
-            for (int b0 = 0; b0 < m; b0 += kWave) {
-                const int i = b0 + tid;
-                const double ratio = (i < m) ? s_rat[i] : NAN;
-                const int bi = (i < m) ? s_bvi[i] : 0;
-                unsigned long long alive = ~0ull;
-                for (;;) {
-                    const bool take = ratio < best - kEps ||
-                                      (fabs(ratio - best) <= kEps && (row == -1 || bi < brow));
-                    const unsigned long long hit = __ballot(take) & alive;
-                    if (hit == 0ull) break;
-                    const int fl = __builtin_amdgcn_readfirstlane(__builtin_ctzll(hit));
-                    best = readlane_f64(ratio, fl);
-                    brow = __builtin_amdgcn_readlane(bi, fl);
-                    row = b0 + fl;
-                    alive = (fl == kWave - 1) ? 0ull : (~0ull << (fl + 1));
-                }
-            }
-            if (tid == 0) s_row = row;
-        }
-        __syncthreads();
-        row = s_row;
-    } else
-    for (;;) {
-        const int brow = (row >= 0) ? basic[row] : 0;
-        int first = INT_MAX;
-#pragma unroll
-        for (int q = 0; q < kCacheR; ++q) {
-            const int i = tid + q * nt;
-            const double ratio = rat[q];  // NaN fails both tests below, as the C# skips the row
-            if (first == INT_MAX && i < m && i > cur &&
-                (ratio < best - kEps ||
-                 (fabs(ratio - best) <= kEps && (row == -1 || bvi[q] < brow))))
-                first = i;
-        }
-        if (first == INT_MAX && !cached_all) {
-            for (int i = tid + kCacheR * nt; i < m; i += nt) {
-                if (i <= cur) continue;
-                const double ui = u[i];
-                if (!(ui > kEps)) continue;
-                const double ratio = xB[i] / ui;
-                if (ratio < best - kEps ||
-                    (fabs(ratio - best) <= kEps && (row == -1 || basic[i] < brow))) {
-                    first = i;
-                    break;
-                }
-            }
-        }
-        const int mine = first;
-        first = block_min_int(first, lds);
-        if (first == INT_MAX) break;
-        if (mine == first) {  // exactly one lane found it: publish its ratio
-            double v = NAN;
-#pragma unroll
-            for (int q = 0; q < kCacheR; ++q)
-                if (tid + q * nt == first) v = rat[q];
-            if (first >= kCacheR * nt) v = xB[first] / u[first];
-            lds_best = v;
-        }
-        __syncthreads();
-        cur = first;
-        row = first;
-        best = lds_best;
-    }
-    if (row < 0) {
-        if (tid == 0) st->status = LPR_UNBOUNDED;  // :178-179
-        return;
-    }
-    const int leavingVar = basic[row];
-    if (leavingVar == e) {
-        if (tid == 0) st->status = LPR_ENTERING_ALREADY_BASIC;  // :182-183
-        return;
-    }
-    const double pivot = u[row];
-    __syncthreads();  // every lane has read basic[row] before it is overwritten
-    if (tid == 0) {
-        const int64_t it = st->iter;
-        if (it < st->log_cap) {
-            log[3 * it] = row;
-            log[3 * it + 1] = e;
-            log[3 * it + 2] = leavingVar;
-        }
-        basic[row] = e;               // :195
-        is_basic[e] = 1;              // nonBasic.Remove(entering) :196
-        is_basic[leavingVar] = 0;     // nonBasic.Add(leavingVar)  :197-198
-        cB[row] = (e < n) ? c[e] : 0.0;  // :205,211
-        st->leaving_row = row;
-        if (fabs(pivot) < kEps) st->status = LPR_PIVOT_TOO_SMALL;  // :267 (after the bookkeeping)
-        else st->iter = it + 1;  // :249
-    }
-    if (fabs(pivot) < kEps) return;
-    for (int i = tid; i < m; i += nt) {
-        fac[i] = (i == row) ? 1.0 / pivot : -u[i] / pivot;  // :272
-        browbuf[i] = Binv[(size_t)row * ldb + i];
-    }
-    for (int i = m + tid; i < ldb; i += nt) browbuf[i] = 0.0;
+    if (st->status != kRunning) return;
+    rev_ratio_body<false>(u, xB, basic, is_basic, cB, c, Binv, ldb, browbuf, fac, log, n, m, st,
+                          s_rat, s_bvi);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -676,6 +478,26 @@ __global__ __launch_bounds__(256) void k_rev_synthetic(double* __restrict__ A, i
         const double v = ru01(seed, 2, 0, (uint64_t)j);
         c[j] = v;
         cOrig[j] = v;
+    }
+}
+
+// At[j, i] = A[i, j] through a 32 x 32 LDS tile (once per solver, after A is in place).
+__global__ __launch_bounds__(256) void k_rev_transpose(const double* __restrict__ A, int lda,
+                                                       double* __restrict__ At, int ldt, int m,
+                                                       int n) {
+    __shared__ double tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+#pragma unroll
+    for (int k = 0; k < 32; k += 8) {
+        const int i = i0 + ty + k, j = j0 + tx;
+        tile[ty + k][tx] = (i < m && j < n) ? A[(size_t)i * lda + j] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 32; k += 8) {
+        const int j = j0 + ty + k, i = i0 + tx;
+        if (j < n && i < ldt) At[(size_t)j * ldt + i] = tile[tx][ty + k];
     }
 }
 
@@ -908,7 +730,7 @@ void rev_launch_iteration(lpr_revised* s, bool snapshot) {
     hipLaunchKernelGGL((k_rev_colsum<kRC, kCBA>), dim3((n + kCBA - 1) / kCBA), dim3(256), (rev_colsum_lds<kRC, kCBA>()), st, s->A, s->lda, m,
                        n, s->y, s->c, s->rcx, 1, s->state);
     hipLaunchKernelGGL(k_rev_enter, dim3(1), dim3(1024), 0, st, s->rcx, s->y, s->is_basic, n, m,
-                       s->state, s->A, s->lda, s->Binv, s->ldb, s->acol, s->u);
+                       s->state, s->At, s->ldb, s->Binv, s->ldb, s->acol, s->u);
     // x_B = B^-1 b (:89) and u = B^-1 a_e (:150; unless the entering variable is a slack) in one
     // pass over B^-1
     hipLaunchKernelGGL(k_rev_rowsum, dim3((m + kRB - 1) / kRB), dim3(256), rev_rowsum_lds(), st, s->Binv, s->ldb,
@@ -923,6 +745,25 @@ void rev_launch_iteration(lpr_revised* s, bool snapshot) {
     constexpr int TR = 8;
     hipLaunchKernelGGL((k_rev_update<TR>), dim3((s->ldb / 2 + 255) / 256, (m + TR - 1) / TR),
                        dim3(256), 0, st, s->Binv, s->ldb, m, s->browbuf, s->fac, s->state);
+}
+
+// revised_fused.hip
+void rev_launch_y(lpr_revised* s);
+void rev_launch_update_y(lpr_revised* s);
+void rev_launch_rc_enter(lpr_revised* s);
+void rev_launch_xu_ratio(lpr_revised* s);
+
+// One iteration of lpr_revised_solve's batches.  Precondition: s->y = c_B B^-1 of the current state
+// (rev_launch_y at the head of a call; afterwards the update pass of every pivot leaves it).
+void rev_launch_iteration_batched(lpr_revised* s) {
+    rev_launch_rc_enter(s);   // rc_j = c_j - y.A_j (:96-98) + entering (:105-121) + GetColumn (:149-151)
+    rev_launch_xu_ratio(s);   // x_B (:89), u (:150) + exits, ratio test (:154-176), bookkeeping (:194-212)
+    rev_launch_update_y(s);   // E * B^-1 (:264-275) + the next iteration's y (:93 = :219)
+}
+
+void rev_launch_transpose_a(lpr_revised* s) {
+    hipLaunchKernelGGL(k_rev_transpose, dim3((s->n + 31) / 32, (s->ldb + 31) / 32), dim3(256), 0,
+                       s->eng->stream, s->A, s->lda, s->At, s->ldb, s->m, s->n);
 }
 
 void rev_launch_extract(lpr_revised* s) {
