@@ -78,6 +78,24 @@ def _pmc_traffic(m: int, n: int, block: int = 1) -> dict:
     return best
 
 
+def _pmc_kernel_traffic(workload: str) -> dict:
+    """Per-kernel HBM-side bytes per dispatch from the newest profiles/r*_{workload}_pmc_summary.json
+    (tools/prof_workload.sh: separate rocprofv3 --pmc passes, FETCH_SIZE doubled for gfx950)."""
+    import glob
+    out = {}
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{workload}_pmc_summary.json"))):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            out = {"source": os.path.relpath(path, ROOT),
+                   "kernels": {k.replace("void ", "").split("<")[0].split("::")[-1]:
+                               int(v["hbm_side_bytes"]) for k, v in d["kernels"].items()
+                               if "lpr::" in k}}
+        except (OSError, ValueError, KeyError):
+            continue
+    return out
+
+
 class Dist:
     """torch.distributed plumbing (backend nccl == RCCL over xGMI); a no-op at world size 1."""
 
@@ -317,6 +335,7 @@ def run_revised(args, D: Dist):
     out = None
     if D.rank == 0:
         tf = flop / (best * 1e-3) / 1e12
+        pmc = _pmc_kernel_traffic("revised") if (m, n) == (4096, 8192) else {}
         cpu = None
         if D.world == 1 and args.cpu_pivots != 0:
             orc = _oracle()
@@ -340,22 +359,32 @@ def run_revised(args, D: Dist):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"dense random LP m={m} n={n} fp64, revised primal simplex "
-                                   f"(order-faithful GEMVs, E*B^-1 update) + B^-1*A on fp64 MFMA",
+                                   f"(order-faithful sums, three launches per iteration) + "
+                                   f"B^-1*A on fp64 MFMA",
                        "m": m, "n": n, "parallelism": f"replica{D.world}"},
             "iteration_hbm": {
-                "note": "one iteration reads B^-1 three times and writes it once (y = c_B B^-1; "
-                        "x_B and u in ONE pass; E*B^-1 in place) and reads A once (reduced "
-                        "costs): 32 m^2 + 8 m n bytes; every sum keeps the C#'s sequential order "
-                        "(a serial add chain per output), which bounds the GEMVs below the "
-                        "streaming rate",
-                "bytes_per_iteration": int(32 * m * m + 8 * m * n),
-                "achieved_gbps": round((32.0 * m * m + 8.0 * m * n) * K / dt_max / 1e9, 1),
-                "frac_of_hbm_peak": round((32.0 * m * m + 8.0 * m * n) * K / dt_max / 1e9
-                                          / HBM_PEAK_GBPS, 4)},
+                "note": "one iteration = three launches: k_rev_rc_enter reads A once (reduced costs, "
+                        "then the entering fold in its last workgroup), k_rev_xu_ratio reads B^-1 "
+                        "once (x_B and u in one pass, then the ratio test), k_rev_update_y reads "
+                        "and writes B^-1 once (E*B^-1 in place and the next y = c_B B^-1 in the "
+                        "same pass): 24 m^2 + 8 m n bytes (round 2: 32 m^2 + 8 m n, y had a pass "
+                        "of its own).  Every sum keeps the C#'s sequential order: a serial chain "
+                        "of m rounded adds per output (~18 us at m = 4096) bounds each pass from "
+                        "below whatever the memory side does",
+                "bytes_per_iteration": int(24 * m * m + 8 * m * n),
+                "achieved_gbps": round((24.0 * m * m + 8.0 * m * n) * K / dt_max / 1e9, 1),
+                "frac_of_hbm_peak": round((24.0 * m * m + 8.0 * m * n) * K / dt_max / 1e9
+                                          / HBM_PEAK_GBPS, 4),
+                "round2_accounting_32m2_8mn_frac": round((32.0 * m * m + 8.0 * m * n) * K / dt_max
+                                                         / 1e9 / HBM_PEAK_GBPS, 4),
+                "pmc_traffic_per_dispatch": pmc.get("kernels"),
+                "pmc_source": pmc.get("source")},
             "roofline": {"bound": "mfma", "kernel": "k_rev_gemm (B^-1 * A, mfma_f64_16x16x4)",
                          "achieved": round(tf, 2), "peak": MFMA_F64_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(tf / MFMA_F64_PEAK_TFLOPS, 4),
-                         "flop_per_launch": flop, "launch_ms": round(best, 4), "traffic": None},
+                         "flop_per_launch": flop, "launch_ms": round(best, 4),
+                         "traffic": (pmc.get("kernels") or {}).get("k_rev_gemm"),
+                         "traffic_source": pmc.get("source")},
             "cpu_baseline": cpu,
         }
     st.destroy()

@@ -45,15 +45,34 @@ __device__ __forceinline__ int lds_load(const int* p) {
     return __atomic_load_n(p, __ATOMIC_RELAXED);
 }
 
-// Walk `len` (<= RC) products of one output, in order.  RC % 16 == 0.
+// The walker's side of the ring: one output per lane (`mine`), its products RC at a time.
+// A full chunk is walked out of registers that already hold its first 16 products; while the LAST
+// 16 are being added, the first 16 of the NEXT chunk are requested (the walker only starts a chunk
+// once the one after it has been filled), so the chain never waits for an LDS round trip at a chunk
+// boundary (32 boundaries x ~0.1 us in k_rev_xu_ratio).  A ragged chunk -- always the last -- is
+// walked element by element.
 template <int RC>
-__device__ __forceinline__ double ring_walk(const double* __restrict__ row, int len, double s) {
-    if (len == RC) {
+struct RingWalker {
+    double2 a[8];
+    bool primed = false;
+
+    // row: this chunk's products; nrow: the next chunk's (nullptr: none)
+    __device__ __forceinline__ double walk(const double* __restrict__ row,
+                                           const double* __restrict__ nrow, int len, double s) {
+        if (len != RC) {
+            for (int k = 0; k < len; ++k) s = s + row[k];
+            primed = false;
+            return s;
+        }
         const double2* __restrict__ r2 = reinterpret_cast<const double2*>(row);
-        double2 a[8];
+        // (no next chunk: the reads of the last group go to the pad behind the row and are dropped)
+        const double2* __restrict__ n2 =
+            nrow ? reinterpret_cast<const double2*>(nrow) : r2 + RC / 2;
+        if (!primed) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) a[u] = r2[u];
-        // the first group is requested in full before the pattern below starts: that is the
+            for (int u = 0; u < 8; ++u) a[u] = r2[u];
+        }
+        // the group in a[] is requested in full before the pattern below starts: that is the
         // distance (8 reads = 16 adds) every later read keeps ahead of its use
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -61,8 +80,8 @@ __device__ __forceinline__ double ring_walk(const double* __restrict__ row, int 
             double2 na[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                na[u] = r2[(k0 + 16) / 2 + u];  // next group: in flight under this group's adds
-                s = s + a[u].x;                 // the C#'s `s += product` (:406, :420)
+                na[u] = (k0 + 16 < RC) ? r2[(k0 + 16) / 2 + u] : n2[u];
+                s = s + a[u].x;  // the C#'s `s += product` (:406, :420, :446)
                 s = s + a[u].y;
             }
             // one LDS read between every two dependent adds: the reads issue in the bubbles of
@@ -75,8 +94,34 @@ __device__ __forceinline__ double ring_walk(const double* __restrict__ row, int 
 #pragma unroll
             for (int u = 0; u < 8; ++u) a[u] = na[u];
         }
-    } else {
-        for (int k = 0; k < len; ++k) s = s + row[k];
+        primed = nrow != nullptr;
+        return s;
+    }
+};
+
+// The walker wave's loop over the chunks of one output per lane.  NOUT rows per slot.
+template <int RC, int S, int NSW, int NOUT>
+__device__ __forceinline__ double ring_consume(const double* ring, RingCtl& ctl, int nchunk,
+                                               int total, int lane, bool mine) {
+    constexpr int ROW = RC + kRingPad;
+    RingWalker<RC> wk;
+    double s = 0.0;
+    auto wait_ready = [&](int ch) {
+        const int need = NSW * (ch / S + 1);
+        while (lds_load(&ctl.ready[ch % S]) < need) __builtin_amdgcn_s_sleep(1);
+    };
+    if (nchunk > 0) wait_ready(0);
+    for (int ch = 0; ch < nchunk; ++ch) {
+        if (ch + 1 < nchunk) wait_ready(ch + 1);
+        asm volatile("" ::: "memory");
+        if (mine) {
+            const double* row = ring + ((size_t)(ch % S) * NOUT + lane) * ROW;
+            const double* nrow =
+                (ch + 1 < nchunk) ? ring + ((size_t)((ch + 1) % S) * NOUT + lane) * ROW : nullptr;
+            s = wk.walk(row, nrow, min(RC, total - ch * RC), s);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) __atomic_store_n(&ctl.done, ch + 1, __ATOMIC_RELAXED);
     }
     return s;
 }
@@ -117,17 +162,7 @@ __global__ __launch_bounds__(64 * (NSW + 1)) void k_rev_update_y(
     if (wave == 0) {
         // ---- the walker ----
         __builtin_amdgcn_s_setprio(3);
-        double s = 0.0;
-        for (int c = 0; c < nchunk; ++c) {
-            const int slot = c % S;
-            const int need = NSW * (c / S + 1);
-            while (lds_load(&ctl.ready[slot]) < need) __builtin_amdgcn_s_sleep(1);
-            asm volatile("" ::: "memory");
-            if (lane < 16)
-                s = ring_walk<RC>(rev_ring + ((size_t)slot * 16 + lane) * ROW, min(RC, m - c * RC), s);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lane == 0) __atomic_store_n(&ctl.done, c + 1, __ATOMIC_RELAXED);
-        }
+        const double s = ring_consume<RC, S, NSW, 16>(rev_ring, ctl, nchunk, m, lane, lane < 16);
         if (lane < 16 && j0 + lane < m) y[j0 + lane] = s;
         return;
     }
@@ -263,17 +298,7 @@ __global__ __launch_bounds__(64 * (NSW + 1)) void k_rev_rc_enter(
     if (wave == 0) {
         __builtin_amdgcn_s_setprio(3);
         if (lane == 0) stamp_min(dbg, 0);
-        double s = 0.0;
-        for (int ch = 0; ch < nchunk; ++ch) {
-            const int slot = ch % S;
-            const int need = NSW * (ch / S + 1);
-            while (lds_load(&ctl.ready[slot]) < need) __builtin_amdgcn_s_sleep(1);
-            asm volatile("" ::: "memory");
-            if (lane < 32)
-                s = ring_walk<RC>(rev_ring + ((size_t)slot * 32 + lane) * ROW, min(RC, m - ch * RC), s);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lane == 0) __atomic_store_n(&ctl.done, ch + 1, __ATOMIC_RELAXED);
-        }
+        const double s = ring_consume<RC, S, NSW, 32>(rev_ring, ctl, nchunk, m, lane, lane < 32);
         if (lane < 32 && j0 + lane < n) st_sc1(rcx + j0 + lane, c[j0 + lane] - s);  // :97
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) stamp_max(dbg, 1);
@@ -345,11 +370,11 @@ __global__ __launch_bounds__(64 * (NSW + 1)) void k_rev_rc_enter(
 // pass over B^-1: 16 rows per workgroup, lanes 0..15 of the walker chain the rows against b,
 // lanes 16..31 the same rows against a_e.  Then, in the workgroup that arrives last, the loop
 // head's exits, the ratio fold, the bookkeeping and the eta column (rev_ratio_body).
-//   stagers (8 waves): a wave-instruction is one row's 128 columns of the chunk (1 KB contiguous);
-//     wave w stages rows 2w, 2w + 1; loads run two chunks ahead of the ring fill.
+//   stagers (kXuNSW waves): a wave-instruction is one row's 128 columns of the chunk (1 KB
+//     contiguous); wave w stages 16 / kXuNSW rows; loads run four chunks ahead of the ring fill.
 // Algorithmic bytes: 8 * m^2.
 constexpr int kXuRC = 128;
-constexpr int kXuNSW = 8;
+constexpr int kXuNSW = 8;   // stager waves (16 / kXuNSW rows each); the tail wants >= 512 threads at m = 4096
 __global__ __launch_bounds__(64 * (kXuNSW + 1)) void k_rev_xu_ratio(
     const double* __restrict__ Binv, int ld, int m, int n, const double* __restrict__ b,
     double* __restrict__ xB, const double* __restrict__ acol, double* __restrict__ u,
@@ -377,18 +402,8 @@ __global__ __launch_bounds__(64 * (kXuNSW + 1)) void k_rev_xu_ratio(
     if (wave == 0) {
         __builtin_amdgcn_s_setprio(3);
         if (lane == 0) stamp_min(dbg, 4);
-        double s = 0.0;
         const bool mine = lane < 16 || (two && lane < 32);
-        for (int ch = 0; ch < nchunk; ++ch) {
-            const int slot = ch % S;
-            const int need = NSW * (ch / S + 1);
-            while (lds_load(&ctl.ready[slot]) < need) __builtin_amdgcn_s_sleep(1);
-            asm volatile("" ::: "memory");
-            if (mine)
-                s = ring_walk<RC>(rev_ring + ((size_t)slot * 32 + lane) * ROW, min(RC, m - ch * RC), s);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lane == 0) __atomic_store_n(&ctl.done, ch + 1, __ATOMIC_RELAXED);
-        }
+        const double s = ring_consume<RC, S, NSW, 32>(rev_ring, ctl, nchunk, m, lane, mine);
         if (lane < 16 && row0 + lane < m) st_sc1(xB + row0 + lane, s);
         if (two && lane >= 16 && lane < 32 && row0 + lane - 16 < m) st_sc1(u + row0 + lane - 16, s);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -396,21 +411,24 @@ __global__ __launch_bounds__(64 * (kXuNSW + 1)) void k_rev_xu_ratio(
         if (lane == 0 && arrive_is_last(&st->arrive_xu, (int)gridDim.x)) s_last = 1;
     } else {
         const int w = wave - 1;
+        constexpr int RPW = 16 / NSW;   // rows a stager wave stages: w * RPW ...
         struct Regs {
-            double2 r0, r1;   // rows 2w, 2w + 1: columns k0 + 2 lane, + 1
+            double2 r[RPW];   // columns k0 + 2 lane, + 1 of those rows
             double2 bv, av;
         };
         constexpr int D = 4;   // chunks the loads run ahead of the ring fill (D + 1 register sets)
         Regs rg[D + 1];
         const int ld2 = ld >> 1;
         const double2* __restrict__ B2 = reinterpret_cast<const double2*>(Binv);
-        const int ia = row0 + 2 * w, ib = ia + 1;
         auto load_chunk = [&](int ch, Regs& g) {
             const int k = ch * RC + 2 * lane;   // first of this lane's two columns
             const bool ok = ch < nchunk && k < ld;
             const double2 z = make_double2(0.0, 0.0);
-            g.r0 = (ok && ia < m) ? B2[(size_t)ia * ld2 + (k >> 1)] : z;
-            g.r1 = (ok && ib < m) ? B2[(size_t)ib * ld2 + (k >> 1)] : z;
+#pragma unroll
+            for (int q = 0; q < RPW; ++q) {
+                const int i = row0 + w * RPW + q;
+                g.r[q] = (ok && i < m) ? B2[(size_t)i * ld2 + (k >> 1)] : z;
+            }
             g.bv.x = (ok && k < m) ? b[k] : 0.0;
             g.bv.y = (ok && k + 1 < m) ? b[k + 1] : 0.0;
             g.av = z;
@@ -425,16 +443,15 @@ __global__ __launch_bounds__(64 * (kXuNSW + 1)) void k_rev_xu_ratio(
             asm volatile("" ::: "memory");
             double* __restrict__ tile = rev_ring + (size_t)slot * 32 * ROW;
             // M[i, j] * v[j], rounded as the C# rounds it before the add (:406)
-            double2 p;
-            p.x = g.r0.x * g.bv.x; p.y = g.r0.y * g.bv.y;
-            *reinterpret_cast<double2*>(tile + (2 * w) * ROW + 2 * lane) = p;
-            p.x = g.r1.x * g.bv.x; p.y = g.r1.y * g.bv.y;
-            *reinterpret_cast<double2*>(tile + (2 * w + 1) * ROW + 2 * lane) = p;
-            if (two) {
-                p.x = g.r0.x * g.av.x; p.y = g.r0.y * g.av.y;
-                *reinterpret_cast<double2*>(tile + (16 + 2 * w) * ROW + 2 * lane) = p;
-                p.x = g.r1.x * g.av.x; p.y = g.r1.y * g.av.y;
-                *reinterpret_cast<double2*>(tile + (16 + 2 * w + 1) * ROW + 2 * lane) = p;
+#pragma unroll
+            for (int q = 0; q < RPW; ++q) {
+                double2 p;
+                p.x = g.r[q].x * g.bv.x; p.y = g.r[q].y * g.bv.y;
+                *reinterpret_cast<double2*>(tile + (w * RPW + q) * ROW + 2 * lane) = p;
+                if (two) {
+                    p.x = g.r[q].x * g.av.x; p.y = g.r[q].y * g.av.y;
+                    *reinterpret_cast<double2*>(tile + (16 + w * RPW + q) * ROW + 2 * lane) = p;
+                }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (lane == 0) __hip_atomic_fetch_add(&ctl.ready[slot], 1, __ATOMIC_RELAXED,

@@ -218,7 +218,8 @@ __device__ __forceinline__ void rev_ratio_body(const double* __restrict__ u,
     // x ~9 takes of the 23 us this kernel took at m = 4096).
     __shared__ int s_row;
     if (dbg && tid == 0) atomicMax(dbg + 9, (unsigned long long)__builtin_amdgcn_s_memrealtime());
-    if (m <= kRatioLds) {
+    const bool in_lds = m <= kRatioLds && cached_all;  // every row's ratio is in a register of its lane
+    if (in_lds) {
 #pragma unroll
         for (int q = 0; q < kCacheR; ++q) {
             const int i = tid + q * nt;
@@ -330,7 +331,6 @@ __device__ __forceinline__ void rev_ratio_body(const double* __restrict__ u,
         return;
     }
     if (dbg && tid == 0) atomicMax(dbg + 10, (unsigned long long)__builtin_amdgcn_s_memrealtime());
-    const bool in_lds = m <= kRatioLds;
     const int leavingVar = in_lds ? s_bvi[row] : basic[row];
     if (leavingVar == e) {
         if (tid == 0) st->status = LPR_ENTERING_ALREADY_BASIC;  // :182-183
