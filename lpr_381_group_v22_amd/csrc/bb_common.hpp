@@ -21,13 +21,17 @@ enum : int32_t {
 
 // One child sub-problem being evaluated (device memory, one per slot of the current batch).
 struct BBSlot {
-    double* cur;       // current tableau ("tableaux.Last()"), rows x ld
-    double* nxt;       // the other buffer of the ping-pong pair: the previous tableau
+    double* cur;       // current tableau ("tableaux.Last()"), rows x ld: pivots are applied IN PLACE
+    double* nxt;       // backup buffer: the old contents of the rows the last pivot changed, kept
+                       // only when that pivot may still be dropped (:395-400)
     int32_t rows, cols;
     int32_t state;
     int32_t pivots;    // tableaux.Count - 1
     int32_t pr, pc;    // pivot chosen by k_bb_select for the pending update
-    int32_t do_update; // 1: k_bb_update must run for this slot, then cur/nxt are swapped
+    int32_t do_update; // 1: k_bb_update must apply the pivot (pr, pc) to the rows of the row list
+    int32_t backup;    // 1: ... and first save those rows into nxt (the pivot may be dropped)
+    int32_t restore;   // 1: the last pivot IS dropped: k_bb_update copies the saved rows back
+    int32_t nlist;     // rows in this slot's row list (rows with a non-zero factor + the pivot row)
     int32_t reverse;   // constraint type of the branching row (1: ">=", AddConstraint :774-775)
     int32_t var;       // branching variable
     int32_t crow;      // index of the appended constraint row
@@ -68,6 +72,7 @@ struct lpr_bb {
     int32_t* bkey = nullptr;          // slot_cap x ld   row of its first 1.0 (or rows)
     int32_t* blist = nullptr;         // slot_cap x ld   sorted basic columns
     int32_t* bcount = nullptr;        // slot_cap
+    int32_t* rowlist = nullptr;       // slot_cap x rows_cap: rows the pending pivot changes
     int32_t* trace = nullptr;         // slot_cap x trace_cap x 3 (phase, row, col)
     int trace_cap = 0;
     double* info = nullptr;           // slot_cap x (nvars + 1): z, decision values

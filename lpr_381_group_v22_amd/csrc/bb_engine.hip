@@ -64,6 +64,8 @@ static void bb_release_device(lpr_bb* b) {
     b->nodes.clear();
     hipFree(b->d_slots); hipFree(b->rowbuf); hipFree(b->colbuf); hipFree(b->bflag);
     hipFree(b->bkey); hipFree(b->blist); hipFree(b->bcount); hipFree(b->trace); hipFree(b->info);
+    hipFree(b->rowlist);
+    b->rowlist = nullptr;
     hipFree(b->d_running);
     if (b->h_slots) hipHostFree(b->h_slots);
     if (b->h_info) hipHostFree(b->h_info);
@@ -128,6 +130,8 @@ static int bb_ensure_slots(lpr_bb* b, int need) {
     LPR_HIP(hipStreamSynchronize(b->eng->stream));
     hipFree(b->d_slots); hipFree(b->rowbuf); hipFree(b->colbuf); hipFree(b->bflag);
     hipFree(b->bkey); hipFree(b->blist); hipFree(b->bcount); hipFree(b->trace); hipFree(b->info);
+    hipFree(b->rowlist);
+    b->rowlist = nullptr;
     if (b->h_slots) hipHostFree(b->h_slots);
     if (b->h_info) hipHostFree(b->h_info);
     b->d_slots = b->h_slots = nullptr;
@@ -144,6 +148,7 @@ static int bb_ensure_slots(lpr_bb* b, int need) {
     LPR_HIP(hipMalloc(&b->bkey, S * b->ld * sizeof(int32_t)));
     LPR_HIP(hipMalloc(&b->blist, S * b->ld * sizeof(int32_t)));
     LPR_HIP(hipMalloc(&b->bcount, S * sizeof(int32_t)));
+    LPR_HIP(hipMalloc(&b->rowlist, S * b->rows_cap * sizeof(int32_t)));
     LPR_HIP(hipMalloc(&b->trace, S * b->trace_cap * 3 * sizeof(int32_t)));
     LPR_HIP(hipMalloc(&b->info, S * (b->nvars + 1) * sizeof(double)));
     LPR_HIP(hipHostMalloc(&b->h_info, S * (b->nvars + 1) * sizeof(double)));
@@ -281,7 +286,7 @@ static int bb_expand(lpr_bb* b, int count, const int32_t* parent_ids, const int3
     int64_t guard = 0;
     for (;;) {
         // k_bb_select and k_bb_update always run as a pair: a select that starts a pivot sets
-        // do_update, and the NEXT select swaps cur/nxt on the strength of that flag
+        // do_update (and backup / restore) for the update that follows it
         for (int k = 0; k < poll; ++k) bb_launch_pivot_step(b, count, rows_max, cols_max, ++queued);
         LPR_HIP(hipGetLastError());
         LPR_HIP(hipMemcpyAsync(b->h_running, b->d_running, 2 * sizeof(int32_t),
@@ -300,8 +305,9 @@ static int bb_expand(lpr_bb* b, int count, const int32_t* parent_ids, const int3
         }
     }
     b->last_steps = b->h_running[1];
-    // the loop only ends when no slot is running; the select that finishes a slot leaves
-    // do_update = 0, so every cur/nxt swap is settled here
+    // the loop only ends when no slot is running: the select that finishes a slot leaves
+    // do_update = 0, and a dropped last pivot (restore) has been undone by the update kernel of the
+    // same step
     bb_launch_round(b, count, rows_max, 0);  // RoundAllTableaux(newTableaux) :1124 / :1187
     LPR_HIP(hipGetLastError());
     LPR_HIP(hipMemcpyAsync(b->h_slots, b->d_slots, (size_t)count * sizeof(BBSlot),

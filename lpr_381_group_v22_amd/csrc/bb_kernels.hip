@@ -14,7 +14,8 @@
 //   k_bb_round(_clean) RoundTableau (:552-567) (+ the -0 -> +0 pass of DoDualSimplex :307-313)
 //   k_bb_select        one DoDualSimplex loop head (:305-400): phase logic, PerformDualPivot
 //                      (:115-160) / PerformPrimalPivot (:203-253) selection, pivot row normalise
-//   k_bb_update        the out-of-place row elimination of both pivots (:174-192, :255-271)
+//   k_bb_update        the row elimination of both pivots (:174-192, :255-271), in place, only the
+//                      rows whose factor is not zero
 //   k_bb_node_info     GetObjective (:892-897) + decision values (:807-827 / :899-921)
 #include "bb_common.hpp"
 
@@ -314,31 +315,28 @@ __global__ __launch_bounds__(1024) void k_bb_select(BBSlot* slots, double* __res
                                                     double* __restrict__ colbuf_all, int ld,
                                                     int rows_cap, int32_t* __restrict__ trace_all,
                                                     int trace_cap, int32_t* running,
-                                                    int step_no) {
+                                                    int step_no,
+                                                    int32_t* __restrict__ rowlist_all) {
     __shared__ double lds_v[16];
     __shared__ int lds_i[16];
+    __shared__ int s_cnt;
     BBSlot* sp = &slots[blockIdx.x];
     const int tid = threadIdx.x, nt = blockDim.x;
 
     // snapshot the header (thread 0 rewrites it at the end)
     double* cur = sp->cur;
-    double* nxt = sp->nxt;
     int state = sp->state;
     int pivots = sp->pivots;
     int trace_n = sp->trace_n;
-    const int had_update = sp->do_update;
+    const int had_flags = sp->do_update | sp->restore;
     const int R = sp->rows, C = sp->cols;
     __syncthreads();
-    if (had_update) {  // the previous k_bb_update wrote the new tableau into nxt
-        double* t = cur;
-        cur = nxt;
-        nxt = t;
-    }
+    // (pivots are applied in place: `cur` is the child's tableau for its whole life, `nxt` only
+    // ever holds the rows saved for a pivot that may be dropped)
     if (state >= kBBSolved) {
-        if (tid == 0 && had_update) {
-            sp->cur = cur;
-            sp->nxt = nxt;
+        if (tid == 0 && had_flags) {
             sp->do_update = 0;
+            sp->restore = 0;
         }
         return;
     }
@@ -346,6 +344,7 @@ __global__ __launch_bounds__(1024) void k_bb_select(BBSlot* slots, double* __res
     double* __restrict__ rowbuf = rowbuf_all + (size_t)blockIdx.x * ld;
     double* __restrict__ colbuf = colbuf_all + (size_t)blockIdx.x * rows_cap;
     int do_update = 0, pr = -1, pc = -1;
+    int backup = 0, restore = 0, nlist = sp->nlist;
     int tr_phase = -1;  // trace entry to append: 0 dual, 1 primal, 2 "last tableau dropped"
     const int rhs = C - 1;
 
@@ -503,9 +502,10 @@ __global__ __launch_bounds__(1024) void k_bb_select(BBSlot* slots, double* __res
                 if (pivots == 0) {
                     state = kBBFailed;  // pivotColumns.RemoveAt(-1) throws
                 } else {
-                    double* t = cur;  // tableaux.RemoveAt(Count - 1): back to the previous one
-                    cur = nxt;
-                    nxt = t;
+                    // tableaux.RemoveAt(Count - 1): back to the previous tableau -- the rows the
+                    // last pivot changed were saved (backup below: this exit is only reachable
+                    // behind a pivot that kept them) and k_bb_update copies them back
+                    restore = 1;
                     pivots -= 1;
                     tr_phase = 2;
                     state = kBBSolved;
@@ -519,12 +519,46 @@ __global__ __launch_bounds__(1024) void k_bb_select(BBSlot* slots, double* __res
     if (do_update) {  // normalised pivot row (:174-178 / :257-261) and the factor column
         const double p = cur[(size_t)pr * ld + pc];
         const double* __restrict__ prow = cur + (size_t)pr * ld;
+        int nonfinite = 0;
         for (int j = tid; j < ld; j += nt) {
             double v = (j < C) ? prow[j] / p : 0.0;
             if (v == 0.0) v = 0.0;  // `== -0.0` is true for both zeros
             rowbuf[j] = v;
+            if (!(fabs(v) < INFINITY)) nonfinite = 1;
         }
-        for (int i = tid; i < R; i += nt) colbuf[i] = cur[(size_t)i * ld + pc];
+        nonfinite = __syncthreads_or(nonfinite);
+        double prhs = prow[rhs] / p;
+        if (prhs == 0.0) prhs = 0.0;
+        if (tid == 0) s_cnt = 0;
+        __syncthreads();
+        // The pivot changes row i only where its factor f_i = T[i, pc] is not zero: x - (0 * p_j)
+        // is x for every finite p_j (the stored zeros are all +0, :334-340).  Those rows -- and the
+        // pivot row -- go on the slot's row list; k_bb_update touches nothing else.  A B&B child
+        // tableau is ~90 % zeros and so are its pivot columns: 13 % of the rows on the bench
+        // instance.  (A non-finite entry in the pivot row: every row is listed, 0 * inf is NaN.)
+        // cont: the tableau AFTER this pivot still has a right-hand side that fails `>= -1e-9`
+        // (the value k_bb_update will store, formed the same way): the dual loop then goes on or
+        // ends infeasible (:315-331) -- either way that tableau is never the one :395-400 drops,
+        // so its old rows need not be kept.
+        int32_t* __restrict__ list = rowlist_all + (size_t)blockIdx.x * rows_cap;
+        int cont = 0;
+        for (int i = tid; i < R; i += nt) {
+            const double f = cur[(size_t)i * ld + pc];
+            colbuf[i] = f;
+            if (nonfinite || f != 0.0 || i == pr) list[atomicAdd(&s_cnt, 1)] = i;
+            double nr;
+            if (i == pr) {
+                nr = prhs;
+            } else {
+                const double prod = f * prhs;
+                nr = cur[(size_t)i * ld + rhs] - prod;
+            }
+            if (nr == 0.0) nr = 0.0;
+            if (!(nr >= -1e-9)) cont = 1;
+        }
+        cont = __syncthreads_or(cont);
+        nlist = s_cnt;
+        backup = (tr_phase == 0 && cont) ? 0 : 1;
         pivots += 1;
     }
 
@@ -538,13 +572,14 @@ __global__ __launch_bounds__(1024) void k_bb_select(BBSlot* slots, double* __res
             }
             trace_n += 1;
         }
-        sp->cur = cur;
-        sp->nxt = nxt;
         sp->state = state;
         sp->pivots = pivots;
         sp->pr = pr;
         sp->pc = pc;
         sp->do_update = do_update;
+        sp->backup = backup;
+        sp->restore = restore;
+        sp->nlist = nlist;
         sp->trace_n = trace_n;
         if (old_state < kBBSolved && state >= kBBSolved) atomicSub(running, 1);
         // running[1]: the last step of this batch that found a child still at work (the host sizes
@@ -555,44 +590,68 @@ __global__ __launch_bounds__(1024) void k_bb_select(BBSlot* slots, double* __res
 
 __device__ __forceinline__ int align_up_dev(int x) { return (x + kLdAlign - 1) / kLdAlign * kLdAlign; }
 
-// grid (ceil(ld2/256), ceil(rows_max/TR), nslots).  Out-of-place like the C# (a fresh tableau per
-// pivot): nxt = cur - colbuf (x) rowbuf, the pivot row replaced by the normalised one, every value
-// passed through the -0 -> +0 rule the C# applies to each new tableau (:334-340, :355-361).
+// grid (1, ceil(rows_max/TR), nslots).  The pivot of :174-192 / :255-271 applied IN PLACE to the
+// rows of the slot's row list (the rows whose factor is not zero, and the pivot row): TR listed
+// rows per workgroup, all columns.  new = old - (f_i * p_j) -- product rounded, then the difference
+// -- the pivot row replaced by the normalised one, every value through the -0 -> +0 rule the C#
+// applies to each new tableau (:334-340, :355-361).  The C# builds a fresh tableau per pivot; the
+// only use it ever makes of the previous one is :395-400 (drop the last tableau): when that can
+// still happen the old rows are saved to slot.nxt first (backup), and a dropped pivot is undone by
+// copying them back (restore).
+// Algorithmic bytes per pivot: 2 * 8 * R * C; moved: 2 (3 with backup) * 8 * nlist * C.
 template <int TR>
 __global__ __launch_bounds__(256) void k_bb_update(const BBSlot* __restrict__ slots,
                                                    const double* __restrict__ rowbuf_all,
-                                                   const double* __restrict__ colbuf_all, int ld,
+                                                   const double* __restrict__ colbuf_all,
+                                                   const int32_t* __restrict__ rowlist_all, int ld,
                                                    int rows_cap) {
     const BBSlot& s = slots[blockIdx.z];
-    if (!s.do_update) return;
+    if (!s.do_update && !s.restore) return;
+    const int nl = s.nlist;
+    const int k0 = blockIdx.y * TR;
+    if (k0 >= nl) return;
     const int ld2 = ld >> 1;
-    const int c2 = blockIdx.x * blockDim.x + threadIdx.x;
-    const int i0 = blockIdx.y * TR;
-    if (c2 >= ld2 || i0 >= s.rows) return;
-    if (2 * c2 >= align_up_dev(s.cols)) return;  // nothing but padding beyond
-    const double2 pr = reinterpret_cast<const double2*>(rowbuf_all + (size_t)blockIdx.z * ld)[c2];
+    const int ncol2 = align_up_dev(s.cols) >> 1;
+    const int32_t* __restrict__ list = rowlist_all + (size_t)blockIdx.z * rows_cap;
+    int idx[TR];
+#pragma unroll
+    for (int k = 0; k < TR; ++k) idx[k] = (k0 + k < nl) ? list[k0 + k] : -1;
+    double2* __restrict__ T2 = reinterpret_cast<double2*>(s.cur);
+    double2* __restrict__ bak = reinterpret_cast<double2*>(s.nxt);
+    if (s.restore) {
+        for (int c2 = threadIdx.x; c2 < ncol2; c2 += blockDim.x)
+#pragma unroll
+            for (int k = 0; k < TR; ++k)
+                if (idx[k] >= 0) T2[(size_t)idx[k] * ld2 + c2] = bak[(size_t)idx[k] * ld2 + c2];
+        return;
+    }
+    const double2* __restrict__ prow2 = reinterpret_cast<const double2*>(rowbuf_all + (size_t)blockIdx.z * ld);
     const double* __restrict__ colbuf = colbuf_all + (size_t)blockIdx.z * rows_cap;
-    const double2* __restrict__ in = reinterpret_cast<const double2*>(s.cur);
-    double2* __restrict__ out = reinterpret_cast<double2*>(s.nxt);
     const int r = s.pr;
-    double2 x[TR];
+    const bool keep = s.backup != 0;
+    double f[TR];
 #pragma unroll
-    for (int k = 0; k < TR; ++k)
-        if (i0 + k < s.rows) x[k] = in[(size_t)(i0 + k) * ld2 + c2];
+    for (int k = 0; k < TR; ++k) f[k] = (idx[k] >= 0) ? colbuf[idx[k]] : 0.0;
+    for (int c2 = threadIdx.x; c2 < ncol2; c2 += blockDim.x) {
+        const double2 pr = prow2[c2];
+        double2 x[TR];
 #pragma unroll
-    for (int k = 0; k < TR; ++k) {
-        const int i = i0 + k;
-        if (i < s.rows) {
-            const double f = colbuf[i];
-            const double px = f * pr.x;
-            const double py = f * pr.y;
-            double2 o;
-            o.x = x[k].x - px;
-            o.y = x[k].y - py;
-            if (i == r) o = pr;
-            if (o.x == 0.0) o.x = 0.0;
-            if (o.y == 0.0) o.y = 0.0;
-            out[(size_t)i * ld2 + c2] = o;
+        for (int k = 0; k < TR; ++k)
+            if (idx[k] >= 0) x[k] = T2[(size_t)idx[k] * ld2 + c2];
+#pragma unroll
+        for (int k = 0; k < TR; ++k) {
+            if (idx[k] >= 0) {
+                if (keep) bak[(size_t)idx[k] * ld2 + c2] = x[k];
+                const double px = f[k] * pr.x;
+                const double py = f[k] * pr.y;
+                double2 o;
+                o.x = x[k].x - px;
+                o.y = x[k].y - py;
+                if (idx[k] == r) o = pr;
+                if (o.x == 0.0) o.x = 0.0;
+                if (o.y == 0.0) o.y = 0.0;
+                T2[(size_t)idx[k] * ld2 + c2] = o;
+            }
         }
     }
 }
@@ -686,18 +745,18 @@ void bb_launch_pivot_step(lpr_bb* b, int nslots, int rows_max, int cols_max, int
     hipStream_t st = b->eng->stream;
     const int threads = (rows_max > 256 || cols_max > 256) ? 1024 : 256;
     hipLaunchKernelGGL(k_bb_select, dim3(nslots), dim3(threads), 0, st, b->d_slots, b->rowbuf,
-                       b->colbuf, b->ld, b->rows_cap, b->trace, b->trace_cap, b->d_running, step_no);
-    constexpr int TR = 4;
-    const int ld2 = align_up(cols_max, kLdAlign) / 2;
-    hipLaunchKernelGGL((k_bb_update<TR>), dim3((ld2 + 255) / 256, (rows_max + TR - 1) / TR, nslots),
-                       dim3(256), 0, st, b->d_slots, b->rowbuf, b->colbuf, b->ld, b->rows_cap);
+                       b->colbuf, b->ld, b->rows_cap, b->trace, b->trace_cap, b->d_running, step_no,
+                       b->rowlist);
+    constexpr int TR = 8;
+    hipLaunchKernelGGL((k_bb_update<TR>), dim3(1, (rows_max + TR - 1) / TR, nslots), dim3(256), 0, st,
+                       b->d_slots, b->rowbuf, b->colbuf, b->rowlist, b->ld, b->rows_cap);
 }
 
 void bb_launch_select_only(lpr_bb* b, int nslots, int rows_max, int cols_max) {
     const int threads = (rows_max > 256 || cols_max > 256) ? 1024 : 256;
     hipLaunchKernelGGL(k_bb_select, dim3(nslots), dim3(threads), 0, b->eng->stream, b->d_slots,
                        b->rowbuf, b->colbuf, b->ld, b->rows_cap, b->trace, b->trace_cap,
-                       b->d_running, 0);
+                       b->d_running, 0, b->rowlist);
 }
 
 }  // namespace lpr
