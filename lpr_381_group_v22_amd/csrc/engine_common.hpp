@@ -123,4 +123,5 @@ struct lpr_tableau {
     void* ov = nullptr;               // lpr_overlap_ctx of the overlapped K-pivot path (overlap_kernels.hip)
     void* blk = nullptr;              // lpr_block_ctx of the K-pivots-per-sweep path (block_kernels.hip)
     void* cut = nullptr;              // lpr_cut_ctx of the cutting-plane side path (cut_kernels.hip)
+    void* small = nullptr;            // lpr_small_ctx of the cache-resident path (small_kernels.hip)
 };

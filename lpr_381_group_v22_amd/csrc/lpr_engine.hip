@@ -50,6 +50,15 @@ void blk_launch_update(lpr_tableau* t, int tr);
 // overlap_kernels.hip
 int ov_max_pivots();
 void ov_release(lpr_tableau* t);
+// small_kernels.hip
+bool small_fits(const lpr_tableau* t);
+int small_pivots_per_block();
+void small_release(lpr_tableau* t);
+int small_ensure(lpr_tableau* t);
+int small_upload_state(lpr_tableau* t, int64_t iter, int64_t max_iter);
+int small_set_log_cap(lpr_tableau* t);
+void small_launch_block(lpr_tableau* t);
+int small_poll(lpr_tableau* t, int32_t* status, int64_t* iter);
 int ov_ensure(lpr_tableau* t, bool second_buffer);
 int ov_begin(lpr_tableau* t, int64_t iter, int64_t max_iter);
 int ov_set_log(lpr_tableau* t, int parity);
@@ -182,6 +191,7 @@ static void release_device(lpr_tableau* t) {
     lpr_cut_release(t);
     blk_release(t);
     ov_release(t);
+    small_release(t);
     for (hipEvent_t ev : t->ev) hipEventDestroy(ev);
     t->ev.clear();
     hipFree(t->T);
@@ -357,6 +367,66 @@ static int solve_fused(lpr_tableau* t, const lpr_solve_opts& o, lpr_solve_result
     t->total_pivots = iter;
     res->status = status;
     res->block = 1;
+    res->pivots = iter - start_iter;
+    res->total_pivots = iter;
+    double z = 0.0;
+    LPR_HIP(hipMemcpyAsync(&z, t->T + (t->cols - 1), sizeof(double), hipMemcpyDeviceToHost, s));
+    LPR_HIP(hipStreamSynchronize(s));
+    res->z = z;
+    return status;
+}
+
+// Cache-resident tableaux (R <= 1024, ld <= 2048: small_kernels.hip): the 16 loop heads of a block
+// in ONE workgroup, hand-offs through LDS, then one in-place sweep.  The default for every tableau
+// that fits (opts.variant == 0, opts.block == 0); opts.variant 0x20xx forces it.
+// Measured (bench.py, pivots/s, this path vs heads-then-sweep 0x4008): m = 512 (6.3 MB) 176 k vs
+// 154 k; m = n = 1000 (16 MB) 132 k vs 140 k -- the single workgroup's two gathers per pivot grow
+// with the tableau, so the default stops at kSmallBytes.
+static constexpr size_t kSmallBytes = (size_t)10 << 20;
+static bool use_small(const lpr_tableau* t, const lpr_solve_opts& o) {
+    if (!small_fits(t)) return false;
+    if ((o.variant & 0xff00) == 0x2000) return true;
+    return o.variant == 0 && o.block == 0 &&
+           (size_t)t->rows * t->ld * sizeof(double) <= kSmallBytes;
+}
+
+static int solve_small(lpr_tableau* t, const lpr_solve_opts& o, lpr_solve_result* res) {
+    hipStream_t s = t->eng->stream;
+    int rc = small_ensure(t);
+    if (rc != LPR_OK_OPTIMAL) return rc;
+    const int K = small_pivots_per_block();
+    const int64_t start_iter = t->total_pivots;
+    const int64_t max_iter = o.max_pivots > 0 ? start_iter + o.max_pivots : 0;
+    rc = small_upload_state(t, start_iter, max_iter);
+    if (rc != LPR_OK_OPTIMAL) return rc;
+    // blocks queued between two polls of the control block: 8, doubling up to 64 (a poll idles the
+    // device for a round trip; a block queued behind the end of the solve returns at once)
+    int nb = o.batch > 0 ? (o.batch + K - 1) / K : 8;
+    const int nb_max = o.batch > 0 ? nb : 64;
+    int32_t status = kRunning;
+    int64_t iter = start_iter;
+    while (status == kRunning) {
+        int q = nb;
+        if (max_iter > 0) {  // the blocks the limit can use, + the head that reports the end
+            const int64_t need = (max_iter - iter + K - 1) / K + 1;
+            if (need < q) q = (int)(need < 1 ? 1 : need);
+        }
+        const int64_t log_before = t->log_cap;
+        rc = ensure_log(t, iter + (int64_t)q * K + 1);
+        if (rc != LPR_OK_OPTIMAL) return rc;
+        if (t->log_cap != log_before) {
+            rc = small_set_log_cap(t);
+            if (rc != LPR_OK_OPTIMAL) return rc;
+        }
+        for (int k = 0; k < q; ++k) small_launch_block(t);
+        LPR_HIP(hipGetLastError());
+        rc = small_poll(t, &status, &iter);
+        if (rc != LPR_OK_OPTIMAL) return rc;
+        if (nb < nb_max) nb = nb * 2 < nb_max ? nb * 2 : nb_max;
+    }
+    t->total_pivots = iter;
+    res->status = status;
+    res->block = K;
     res->pivots = iter - start_iter;
     res->total_pivots = iter;
     double z = 0.0;
@@ -889,6 +959,7 @@ int lpr_primal_solve(lpr_tableau* t, const lpr_solve_opts* opts, lpr_solve_resul
     hipStream_t s = e->stream;
     LPR_HIP(hipSetDevice(e->device));
 
+    if (use_small(t, o)) return solve_small(t, o, res);
     if (use_fused(t, o)) return solve_fused(t, o, res);
     {
         // variant 0x60tr: in-place blocked path; 0x50tr or none: the overlapped path

@@ -4,6 +4,8 @@
 
 #include "engine_common.hpp"
 
+#include <climits>
+
 #pragma clang fp contract(off)
 
 namespace lpr {
@@ -58,6 +60,67 @@ __device__ __forceinline__ Cand block_cand_min(Cand c, double* lds_v, int* lds_i
         r = cand_min(r, o);
     }
     return r;
+}
+
+// ------------------------------------------------------------------------------------------
+// The same lexicographic minimum with DPP moves (row-local permutes, then the two row broadcasts of
+// gfx9) instead of six rounds of ds_bpermute, as two plain reductions: the minimum VALUE over the
+// candidates, then the minimum INDEX over the lanes that hold it.  Candidates must not be NaN (a
+// ratio that passed `>= 0`, a Z-row entry that passed `<`); ties go to the lower index as in
+// cand_min; the value returned when there is no candidate is unused by the callers.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_fmin(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int olo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+    const int ohi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+    return fmin(v, __hiloint2double(ohi, olo));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_imin(int i) {
+    return min(i, __builtin_amdgcn_update_dpp(i, i, CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ Cand dpp_wave_cand_min(Cand c) {
+    double v = (c.i >= 0) ? c.v : INFINITY;
+    v = dpp_fmin<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+    v = dpp_fmin<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+    v = dpp_fmin<0x141, 0xf>(v);  // row_half_mirror
+    v = dpp_fmin<0x140, 0xf>(v);  // row_mirror: every row of 16 holds its minimum
+    v = dpp_fmin<0x142, 0xa>(v);  // row_bcast15 into rows 1 and 3
+    v = dpp_fmin<0x143, 0xc>(v);  // row_bcast31 into rows 2 and 3: lane 63 holds the minimum
+    const int vlo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int vhi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    const double vmin = __hiloint2double(vhi, vlo);
+    int i = (c.i >= 0 && c.v == vmin) ? c.i : INT_MAX;
+    i = dpp_imin<0xB1, 0xf>(i);
+    i = dpp_imin<0x4E, 0xf>(i);
+    i = dpp_imin<0x141, 0xf>(i);
+    i = dpp_imin<0x140, 0xf>(i);
+    i = dpp_imin<0x142, 0xa>(i);
+    i = dpp_imin<0x143, 0xc>(i);
+    const int imin = __builtin_amdgcn_readlane(i, 63);
+    Cand r;
+    r.v = vmin;
+    r.i = (imin == INT_MAX) ? -1 : imin;
+    return r;
+}
+
+// Block-wide form: a DPP reduction per wave, one slot per wave in LDS, then every wave reduces the
+// slots itself (one per lane) -- two barriers, no serial walk over the slots.
+__device__ __forceinline__ Cand dpp_block_cand_min(Cand c, double* lds_v, int* lds_i) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    const int nwaves = blockDim.x / kWave;
+    c = dpp_wave_cand_min(c);
+    __syncthreads();  // protect the slots against the previous use
+    if (lane == 0) {
+        lds_v[wave] = c.v;
+        lds_i[wave] = c.i;
+    }
+    __syncthreads();
+    Cand o;
+    o.v = (lane < nwaves) ? lds_v[lane] : 0.0;
+    o.i = (lane < nwaves) ? lds_i[lane] : -1;
+    return dpp_wave_cand_min(o);
 }
 
 // ------------------------------------------------------------------------------------------
