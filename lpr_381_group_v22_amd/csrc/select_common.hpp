@@ -123,6 +123,43 @@ __device__ __forceinline__ Cand dpp_block_cand_min(Cand c, double* lds_v, int* l
     return dpp_wave_cand_min(o);
 }
 
+// The same for workgroups of at most 16 waves, with ONE barrier: the slots alternate between two
+// banks (`bank` = parity of the call count, the caller's), so a wave that is already publishing
+// for the next reduction cannot overwrite a slot another wave still reads; and the second stage
+// reduces 16 lanes, not 64 (four row-local DPP stages instead of six per pass).
+// lds_v / lds_i: 32 entries each.
+__device__ __forceinline__ Cand dpp_block_cand_min16(Cand c, double* lds_v, int* lds_i, int bank) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    const int nwaves = blockDim.x / kWave;
+    c = dpp_wave_cand_min(c);
+    if (lane == 0) {
+        lds_v[bank * 16 + wave] = c.v;
+        lds_i[bank * 16 + wave] = c.i;
+    }
+    __syncthreads();
+    const int l = lane & 15;
+    const bool ok = l < nwaves;
+    const double ov = lds_v[bank * 16 + (ok ? l : 0)];
+    const int oi = ok ? lds_i[bank * 16 + l] : -1;
+    double v = (oi >= 0) ? ov : INFINITY;
+    v = dpp_fmin<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+    v = dpp_fmin<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+    v = dpp_fmin<0x141, 0xf>(v);  // row_half_mirror
+    v = dpp_fmin<0x140, 0xf>(v);  // row_mirror: every lane of the row holds the minimum
+    int i = (oi >= 0 && ov == v) ? oi : INT_MAX;
+    i = dpp_imin<0xB1, 0xf>(i);
+    i = dpp_imin<0x4E, 0xf>(i);
+    i = dpp_imin<0x141, 0xf>(i);
+    i = dpp_imin<0x140, 0xf>(i);
+    Cand r;
+    r.v = v;
+    r.i = (i == INT_MAX) ? -1 : i;
+    // (every row of 16 lanes did the same reduction: the result is wave-uniform; say so)
+    r.i = __builtin_amdgcn_readfirstlane(r.i);
+    return r;
+}
+
 // ------------------------------------------------------------------------------------------
 // Partial results of the next-entering-column arg-min, one per k_pivot_head workgroup.  Two banks,
 // selected by the parity of the pivot counter: head t reads bank (iter & 1) -- written by head t-1

@@ -116,7 +116,7 @@ struct SmallHead {
                 if (j0 + 1 < rhs && z2[u].y < c.v) { c.v = z2[u].y; c.i = j0 + 1; }
             }
         }
-        c = dpp_block_cand_min(c, lds_v, lds_i);
+        c = dpp_block_cand_min16(c, lds_v, lds_i, 0);
         const int e = c.i;
         if (e < 0) {
             pending = LPR_OK_OPTIMAL;
@@ -179,7 +179,7 @@ struct SmallHead {
                 }
             }
         }
-        m = dpp_block_cand_min(m, lds_v, lds_i);
+        m = dpp_block_cand_min16(m, lds_v, lds_i, 1);
         const int r = m.i;
         if (r < 0) {
             pending = LPR_UNBOUNDED;
@@ -292,8 +292,8 @@ __global__ __launch_bounds__(kSmallNT) void k_small_heads(const double* __restri
                                                           SmallState* st,
                                                           unsigned long long* dbg) {
     extern __shared__ __attribute__((aligned(16))) double s_f[];  // [K][Rp]: f_s[i]
-    __shared__ double lds_v[16];
-    __shared__ int lds_i[16];
+    __shared__ double lds_v[32];
+    __shared__ int lds_i[32];
     __shared__ double2 s_pe2[kSmallK];
     __shared__ double2 s_prhs2;
     __shared__ double s_piv, s_f0;
@@ -357,37 +357,44 @@ __global__ __launch_bounds__(256) void k_small_sweep(double* __restrict__ T, int
     const int c2 = blockIdx.x * blockDim.x + threadIdx.x;
     const int i0 = blockIdx.y * TR;
     if (c2 >= ld2) return;
+    // Straight-line code for all K pivots and TR rows: a pivot that was not staged has p = 0 and
+    // f = 0, and x - (0 * 0) is x for every x; a row past the end is computed on row R - 1's data
+    // and not stored.  (With a branch per (pivot, row) the kernel was 424 branches long and every
+    // factor was waited for on its own: 12.6 us for 6.3 MB.)
     double2 p[kSmallK];
     int rs[kSmallK];
 #pragma unroll
     for (int s = 0; s < kSmallK; ++s) {
-        p[s] = (s < kd) ? reinterpret_cast<const double2*>(prow + (size_t)s * ld)[c2]
-                        : make_double2(0.0, 0.0);
+        const double2 v = reinterpret_cast<const double2*>(prow + (size_t)(s < kd ? s : 0) * ld)[c2];
+        p[s].x = (s < kd) ? v.x : 0.0;
+        p[s].y = (s < kd) ? v.y : 0.0;
         rs[s] = (s < kd) ? st->r[s] : -1;
     }
     double2* __restrict__ T2 = reinterpret_cast<double2*>(T);
     double2 x[TR];
+    int ir[TR];
 #pragma unroll
-    for (int k = 0; k < TR; ++k)
-        if (i0 + k < R) x[k] = T2[(size_t)(i0 + k) * ld2 + c2];
+    for (int k = 0; k < TR; ++k) {
+        ir[k] = (i0 + k < R) ? i0 + k : R - 1;
+        x[k] = T2[(size_t)ir[k] * ld2 + c2];
+    }
 #pragma unroll
     for (int s = 0; s < kSmallK; ++s) {
-        if (s < kd) {
+        double f[TR];  // the same for every lane: scalar loads
 #pragma unroll
-            for (int k = 0; k < TR; ++k) {
-                const int i = i0 + k;
-                if (i < R) {
-                    if (i == rs[s]) {
-                        x[k] = p[s];
-                    } else {
-                        const double f = fcol[(size_t)s * Rp + i];
-                        const double px = f * p[s].x;
-                        const double py = f * p[s].y;
-                        x[k].x = x[k].x - px;
-                        x[k].y = x[k].y - py;
-                    }
-                }
-            }
+        for (int k = 0; k < TR; ++k) {
+            const double fv = fcol[(size_t)(s < kd ? s : 0) * Rp + ir[k]];
+            f[k] = (s < kd) ? fv : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < TR; ++k) {
+            const double px = f[k] * p[s].x;
+            const double py = f[k] * p[s].y;
+            const double ox = x[k].x - px;
+            const double oy = x[k].y - py;
+            const bool piv = ir[k] == rs[s];
+            x[k].x = piv ? p[s].x : ox;
+            x[k].y = piv ? p[s].y : oy;
         }
     }
 #pragma unroll
