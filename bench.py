@@ -243,6 +243,19 @@ def run_primal(args, D: Dist):
         if step_ms:
             roof["avg_step_ms"] = round(step_ms, 6)
             roof["steps_timed"] = nsteps
+        if R * C * 8 <= (256 << 20) * 0.5:
+            # cache-resident: an effective rate, not a fraction of the HBM roofline -- a
+            # pivot here is bound by the latency of its dependent steps (two gathers, two arg-min
+            # reductions), not by bytes
+            eff = bytes_per_pivot * value / D.world / 1e9
+            roof.update({"bound": "latency", "achieved": round(eff, 1), "frac": None,
+                         "unit": "GB/s (effective: 2*8*R*C bytes per pivot x pivots/s; the "
+                                 "tableau stays in L2 / Infinity Cache)",
+                         "us_per_pivot": round(1e6 * D.world / value, 3)})
+            if B > 1 and R <= 1024 and (C + 15) // 16 * 16 <= 2048 and args.variant == 0 \
+                    and args.block == 0 and R * ((C + 15) // 16 * 16) * 8 <= (10 << 20):
+                roof["kernel"] = ("k_small_heads (the 16 loop heads of a block in one workgroup) "
+                                  "+ k_small_sweep (in place)")
         roof.update(_pmc_traffic(m, n, B))
         if roof.get("traffic") and (step_ms or kern_ms):
             # what the chip's memory side sustains over a whole step (sweep + heads beside it)

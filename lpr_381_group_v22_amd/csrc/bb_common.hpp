@@ -50,7 +50,8 @@ struct lpr_bb {
     int rows0 = 0, cols0 = 0;   // root tableau shape
     int nvars = 0;
     int max_depth = 0;
-    int rows_cap = 0, ld = 0;   // every node buffer is rows_cap x ld doubles
+    int rows_cap = 0, ld = 0;   // every node buffer is (rows_cap + 2) x ld doubles: the tableau, then
+                                // the two rows k_bb_finish leaves behind it
     size_t buf_elems = 0;
     // node pool
     struct Node {
@@ -58,6 +59,7 @@ struct lpr_bb {
         int rows = 0, cols = 0, depth = 0;
         bool live = false;
         bool big = true;   // rounding the stored tableau again could change it (unknown: yes)
+        bool side = false; // rows rows_cap, rows_cap + 1 of the buffer hold its scan / scores (k_bb_finish)
     };
     std::vector<Node> nodes;          // node id -> buffer
     std::vector<double*> free_bufs;   // recycled device buffers

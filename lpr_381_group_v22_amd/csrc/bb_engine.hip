@@ -29,8 +29,11 @@ int comm_all_gather(lpr_comm* c, const void* send, void* recv, int bytes);
 void bb_launch_copy_in(lpr_bb* b, const double* src, int src_ld, int rows, int cols, double* dst);
 void bb_launch_round(lpr_bb* b, int nslots, int rows_max, int clean);
 void bb_launch_node_info(lpr_bb* b, int count);
-void bb_launch_add_constraint(lpr_bb* b, int nslots, int nparents, int rows_max, int cols_max);
+void bb_launch_add_constraint(lpr_bb* b, int nslots, int nparents, int rows_max, int cols_max,
+                              bool side);
 void bb_launch_pivot_step(lpr_bb* b, int nslots, int rows_max, int cols_max, int step_no);
+void bb_launch_finish(lpr_bb* b, int nslots, int cols_max);
+void bb_launch_gather_info(lpr_bb* b, int count);
 void bb_launch_select_only(lpr_bb* b, int nslots, int rows_max, int cols_max);
 
 // ---- .NET Framework rounding on the host (IsInteger :595-599 works on n values per node) ----
@@ -198,10 +201,20 @@ static int bb_node_info(lpr_bb* b, const int32_t* ids, int count, double* z_out,
     // currentTableaux = RoundAllTableaux(...) :1047.  A node stored by bb_expand has been rounded
     // once already (:1124 / :1187); below 1e11 rounding is idempotent, so the pass is skipped unless
     // a node of the batch holds a larger (or non-finite) entry, or its history is unknown (the root)
-    bool any_big = false;
-    for (int k = 0; k < count; ++k) any_big = any_big || b->nodes[ids[k]].big;
-    if (any_big) bb_launch_round(b, count, rows_max, 0);
-    bb_launch_node_info(b, count);
+    bool any_big = false, all_side = true;
+    for (int k = 0; k < count; ++k) {
+        any_big = any_big || b->nodes[ids[k]].big;
+        all_side = all_side && b->nodes[ids[k]].side;
+    }
+    if (!any_big && all_side) {
+        bb_launch_gather_info(b, count);  // scored by k_bb_finish when they were solved
+    } else {
+        if (any_big) {
+            bb_launch_round(b, count, rows_max, 0);
+            for (int k = 0; k < count; ++k) b->nodes[ids[k]].side = false;  // (re-rounded: stale)
+        }
+        bb_launch_node_info(b, count);
+    }
     LPR_HIP(hipGetLastError());
     LPR_HIP(hipMemcpyAsync(b->h_info, b->info, (size_t)count * (b->nvars + 1) * sizeof(double),
                            hipMemcpyDeviceToHost, st));
@@ -273,7 +286,10 @@ static int bb_expand(lpr_bb* b, int count, const int32_t* parent_ids, const int3
     b->h_running[1] = 0;
     LPR_HIP(hipMemcpyAsync(b->d_running, b->h_running, 2 * sizeof(int32_t), hipMemcpyHostToDevice,
                            st));
-    bb_launch_add_constraint(b, count, nparents, rows_max, cols_max);
+    bool side = true;  // every parent carries its own IdentifyBasicVariables scan
+    for (int k = 0; k < count; ++k)
+        side = side && b->nodes[parent_ids[k]].side && !b->nodes[parent_ids[k]].big;
+    bb_launch_add_constraint(b, count, nparents, rows_max, cols_max, side);
 
     // DoDualSimplex: pivot steps until every child has left the running states
     // Pivot steps queued between polls of the running counter.  A poll idles the device ~50 us; a
@@ -308,7 +324,8 @@ static int bb_expand(lpr_bb* b, int count, const int32_t* parent_ids, const int3
     // the loop only ends when no slot is running: the select that finishes a slot leaves
     // do_update = 0, and a dropped last pivot (restore) has been undone by the update kernel of the
     // same step
-    bb_launch_round(b, count, rows_max, 0);  // RoundAllTableaux(newTableaux) :1124 / :1187
+    // RoundAllTableaux(newTableaux) :1124 / :1187 + what the children will be scored / expanded by
+    bb_launch_finish(b, count, cols_max);
     LPR_HIP(hipGetLastError());
     LPR_HIP(hipMemcpyAsync(b->h_slots, b->d_slots, (size_t)count * sizeof(BBSlot),
                            hipMemcpyDeviceToHost, st));
@@ -334,6 +351,7 @@ static int bb_expand(lpr_bb* b, int count, const int32_t* parent_ids, const int3
             child_ids_out[k] = bb_new_node(b, s.cur, s.rows, s.cols,
                                            b->nodes[parent_ids[k]].depth + 1);
             b->nodes[child_ids_out[k]].big = s.big != 0;
+            b->nodes[child_ids_out[k]].side = s.big == 0;
             b->free_bufs.push_back(s.nxt);
         } else {
             child_ids_out[k] = -1;
@@ -379,7 +397,7 @@ static int bb_create_common(lpr_engine* e, int rows, int cols, int nvars, int ma
     b->max_depth = max_depth;
     b->rows_cap = rows + max_depth;
     b->ld = align_up(cols + max_depth, kLdAlign);
-    b->buf_elems = (size_t)b->rows_cap * b->ld;
+    b->buf_elems = (size_t)(b->rows_cap + 2) * b->ld;
     e->live_bb.push_back(b);
     *out = b;
     return LPR_OK_OPTIMAL;

@@ -203,7 +203,7 @@ __global__ __launch_bounds__(64) void k_bb_basic_scan(const BBSlot* __restrict__
 __global__ __launch_bounds__(1024) void k_bb_eliminate(const BBSlot* __restrict__ slots, int ld,
                                                        const int32_t* __restrict__ bflag,
                                                        const int32_t* __restrict__ bkey,
-                                                       int32_t* __restrict__ blist) {
+                                                       int32_t* __restrict__ blist, int side_row) {
     __shared__ int lds[16];
     __shared__ int s_count;
     const BBSlot& s = slots[blockIdx.x];
@@ -211,8 +211,12 @@ __global__ __launch_bounds__(1024) void k_bb_eliminate(const BBSlot* __restrict_
     const int Rc = s.rows, Cc = s.cols;
     const int R = Rc - 1, C = Cc - 1;
     const int crow = R;
-    const int32_t* __restrict__ flag = bflag + (size_t)s.pscan * ld;
-    const int32_t* __restrict__ key = bkey + (size_t)s.pscan * ld;
+    // side_row >= 0: the parent's IdentifyBasicVariables scan was left in row `side_row` of its own
+    // buffer by k_bb_finish (flags, then keys); otherwise k_bb_basic_scan has just made it
+    const int32_t* __restrict__ pside =
+        reinterpret_cast<const int32_t*>(s.parent + (size_t)(side_row >= 0 ? side_row : 0) * ld);
+    const int32_t* __restrict__ flag = side_row >= 0 ? pside : bflag + (size_t)s.pscan * ld;
+    const int32_t* __restrict__ key = side_row >= 0 ? pside + ld : bkey + (size_t)s.pscan * ld;
     int32_t* __restrict__ list = blist + (size_t)blockIdx.x * ld;
     double* __restrict__ T = s.cur;
     if (tid == 0) s_count = 0;
@@ -656,6 +660,73 @@ __global__ __launch_bounds__(256) void k_bb_update(const BBSlot* __restrict__ sl
     }
 }
 
+// grid (ceil(C/64), nslots), one lane per column.  What happens to a solved child between its last
+// pivot and its own expansion, in ONE pass over it instead of three:
+//   RoundAllTableaux(newTableaux) (:1124 / :1187): every entry rounded in place (k_bb_round);
+//   GetObjective + the decision values (:892-897, :807-827) it is scored by when popped
+//     (k_bb_node_info) -> row rows_cap + 1 of the child's own buffer: { z, x_0 .. };
+//   IdentifyBasicVariables (:642-663) of it AS A PARENT (k_bb_basic_scan) -> row rows_cap: the
+//     flags of all columns, then the keys.
+// Valid while no rounded entry is >= 1e11 or non-finite (slot.big, as in k_bb_round): below that
+// RoundNumber is idempotent, so the second rounding of the pop (:1047) and the roundings the
+// consumers apply on top change nothing; a big node goes through the separate kernels.
+__global__ __launch_bounds__(64) void k_bb_finish(BBSlot* __restrict__ slots, int ld, int rows_cap,
+                                                 int nvars) {
+    BBSlot& s = slots[blockIdx.y];
+    if (s.state != kBBSolved) return;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int R = s.rows, C = s.cols;
+    if (k >= C) return;
+    double* __restrict__ T = s.cur;
+    double sum = 0.0;
+    int key = R, frow = -1;
+    bool big = false;
+    double v0 = 0.0;
+    constexpr int U = 8;  // rows in flight per lane (the sum itself stays in row order)
+    for (int i0 = 0; i0 < R; i0 += U) {
+        double x[U];
+#pragma unroll
+        for (int d = 0; d < U; ++d) x[d] = (i0 + d < R) ? T[(size_t)(i0 + d) * ld + k] : 0.0;
+#pragma unroll
+        for (int d = 0; d < U; ++d) {
+            const int i = i0 + d;
+            if (i < R) {
+                const double v = dn_round4(x[d]);          // :1124 / :1187
+                big = big || !(fabs(v) < 1e11);
+                T[(size_t)i * ld + k] = v;
+                if (i == 0) v0 = v;
+                const double v2 = dn_round4_twice(v);      // working = Round(base) :702, Identify :655
+                sum = sum + v2;
+                if (key == R && v2 == 1.0) key = i;
+                if (frow < 0 && fabs(dn_round4(v) - 1.0) <= kBBEps) frow = i;  // :812-821
+            }
+        }
+    }
+    sum = dn_round4(sum);
+    int32_t* __restrict__ side = reinterpret_cast<int32_t*>(T + (size_t)rows_cap * ld);
+    side[k] = (fabs(sum - 1.0) <= kBBEps) ? 1 : 0;
+    side[ld + k] = key;
+    double* __restrict__ info = T + (size_t)(rows_cap + 1) * ld;
+    if (k == C - 1) info[0] = dn_round4(v0);               // GetObjective :892-897
+    if (k < nvars) {
+        // the right-hand side of that row, rounded as the stored tableau and again by the reader
+        // (the lane of column C - 1 may or may not have rounded it in place yet: the same value
+        // either way below 1e11)
+        info[1 + k] = (frow >= 0) ? dn_round4(dn_round4(T[(size_t)frow * ld + (C - 1)])) : 0.0;
+    }
+    if (big) atomicOr(&s.big, 1);
+}
+
+// grid (ceil((nvars + 1) / 256), count): the scores k_bb_finish left in each node's buffer, packed
+__global__ __launch_bounds__(256) void k_bb_gather_info(const BBSlot* __restrict__ slots, int ld,
+                                                        int rows_cap, int nvars,
+                                                        double* __restrict__ info) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > nvars) return;
+    const BBSlot& s = slots[blockIdx.y];
+    info[(size_t)blockIdx.y * (nvars + 1) + j] = s.cur[(size_t)(rows_cap + 1) * ld + j];
+}
+
 // grid (ceil(nvars/64), count).  info[slot] = { z, x_0 .. x_{nvars-1} }: GetObjective (:892-897)
 // and the "first row whose rounded entry is 1" decision values (:807-827, :899-921; row 0 is
 // part of the scan).
@@ -718,13 +789,25 @@ void bb_launch_node_info(lpr_bb* b, int count) {
                        dim3(64), 0, b->eng->stream, b->d_slots, b->ld, b->nvars, b->info);
 }
 
-void bb_launch_add_constraint(lpr_bb* b, int nslots, int nparents, int rows_max, int cols_max) {
+void bb_launch_finish(lpr_bb* b, int nslots, int cols_max) {
+    hipLaunchKernelGGL(k_bb_finish, dim3((cols_max + 63) / 64, nslots), dim3(64), 0, b->eng->stream,
+                       b->d_slots, b->ld, b->rows_cap, b->nvars);
+}
+
+void bb_launch_gather_info(lpr_bb* b, int count) {
+    hipLaunchKernelGGL(k_bb_gather_info, dim3((b->nvars + 1 + 255) / 256, count), dim3(256), 0,
+                       b->eng->stream, b->d_slots, b->ld, b->rows_cap, b->nvars, b->info);
+}
+
+void bb_launch_add_constraint(lpr_bb* b, int nslots, int nparents, int rows_max, int cols_max,
+                              bool side) {
     hipStream_t st = b->eng->stream;
     const dim3 egrid((b->ld + 255) / 256, (rows_max + kBBRowsPerThread - 1) / kBBRowsPerThread,
                      nslots);
     hipLaunchKernelGGL(k_bb_child_init, egrid, dim3(256), 0, st, b->d_slots, b->ld);
-    hipLaunchKernelGGL(k_bb_basic_scan, dim3((cols_max + 63) / 64, nparents), dim3(64), 0, st,
-                       b->d_slots, b->ld, b->bflag, b->bkey);
+    if (!side)  // (otherwise every parent carries its scan in its own buffer: k_bb_finish)
+        hipLaunchKernelGGL(k_bb_basic_scan, dim3((cols_max + 63) / 64, nparents), dim3(64), 0, st,
+                           b->d_slots, b->ld, b->bflag, b->bkey);
     // (:799 RoundTableau and the -0 pass of :307-313 are applied by child_init / eliminate as they
     // write: no separate pass over the children)
     const size_t elim_lds = (size_t)b->ld * sizeof(int);  // <= kBBEliminateLdsMax (lpr_bb_create)
@@ -738,7 +821,7 @@ void bb_launch_add_constraint(lpr_bb* b, int nslots, int nparents, int rows_max,
         }
     }
     hipLaunchKernelGGL(k_bb_eliminate, dim3(nslots), dim3(1024), elim_lds, st,
-                       b->d_slots, b->ld, b->bflag, b->bkey, b->blist);
+                       b->d_slots, b->ld, b->bflag, b->bkey, b->blist, side ? b->rows_cap : -1);
 }
 
 void bb_launch_pivot_step(lpr_bb* b, int nslots, int rows_max, int cols_max, int step_no) {
