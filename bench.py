@@ -472,6 +472,7 @@ def run_bb(args, D: Dist):
         Rm, Cm = R0 + levels / 2.0, C0 + levels / 2.0
         bytes_per_pivot = 2 * 8 * Rm * Cm
         achieved = res["pivots"] * bytes_per_pivot / dt_max / 1e9
+        pmc = _pmc_kernel_traffic("bb") if (nv, nc, levels) == (512, 64, 9) else {}
         cpu = None
         if D.world == 1 and args.cpu_pivots != 0:
             orc = _oracle()
@@ -523,12 +524,20 @@ def run_bb(args, D: Dist):
             "roofline": {"bound": "hbm", "kernel": "k_bb_update (batched out-of-place pivot of "
                                                    "all live children)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                         # PMC: bytes of the median working k_bb_update dispatch (one pivot step of
+                         # every live child of a batch); all kernels in pmc_traffic_per_dispatch
+                         "traffic": (pmc.get("kernels") or {}).get("k_bb_update"),
+                         "traffic_source": pmc.get("source"),
+                         "pmc_traffic_per_dispatch": pmc.get("kernels"),
                          "bytes_per_pivot": int(bytes_per_pivot),
-                         "note": "whole-job form: bytes of all sub-problem pivots / wall time "
-                                 "(child set-up, selection kernels, host polls included); a child "
-                                 "tableau is ~%.1f MB, %d live children at the widest level stay "
-                                 "out of L2" % (Rm * Cm * 8 / 1e6, 1 << (levels - 1))},
+                         "note": "whole-job form: ALGORITHMIC bytes of all sub-problem pivots (2*8*R*C "
+                                 "each, SURVEY 8d) / wall time (child set-up, selection kernels, host "
+                                 "polls included).  The pivots are applied in place to the rows whose "
+                                 "factor is not zero (~13 %% of them on this instance), so the bytes "
+                                 "that MOVE are far fewer: see traffic.  A child tableau is ~%.1f MB, "
+                                 "%d live children at the widest level"
+                                 % (Rm * Cm * 8 / 1e6, 1 << (levels - 1))},
             "cpu_baseline": cpu,
         }
     if comm is not None:

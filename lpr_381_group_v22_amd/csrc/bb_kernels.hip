@@ -682,7 +682,7 @@ __global__ __launch_bounds__(64) void k_bb_finish(BBSlot* __restrict__ slots, in
     int key = R, frow = -1;
     bool big = false;
     double v0 = 0.0;
-    constexpr int U = 8;  // rows in flight per lane (the sum itself stays in row order)
+    constexpr int U = 16;  // rows in flight per lane (the sum itself stays in row order)
     for (int i0 = 0; i0 < R; i0 += U) {
         double x[U];
 #pragma unroll
@@ -693,7 +693,9 @@ __global__ __launch_bounds__(64) void k_bb_finish(BBSlot* __restrict__ slots, in
             if (i < R) {
                 const double v = dn_round4(x[d]);          // :1124 / :1187
                 big = big || !(fabs(v) < 1e11);
-                T[(size_t)i * ld + k] = v;
+                // (most entries are zeros or come from rows no pivot touched since child_init
+                // rounded them: only a value whose bits change is written back)
+                if (__double_as_longlong(v) != __double_as_longlong(x[d])) T[(size_t)i * ld + k] = v;
                 if (i == 0) v0 = v;
                 const double v2 = dn_round4_twice(v);      // working = Round(base) :702, Identify :655
                 sum = sum + v2;

@@ -504,3 +504,56 @@ def test_pivot_log_growth_is_crossed_in_an_oracle_checked_solve(engine, oracle, 
     assert tab2.read().tobytes() == tab.read().tobytes()
     tab.destroy()
     tab2.destroy()
+
+
+SMALL = 0x2000  # csrc/small_kernels.hip forced (the default up to 10 MB)
+
+
+@pytest.mark.parametrize("m,n,pivots", [(1023, 1000, 90), (1000, 1000, 120), (700, 1300, 200),
+                                        (37, 11, 0), (1, 1, 0), (3, 900, 0), (600, 2, 0)],
+                         ids=["max-rows-1024", "16MB", "wide", "tiny", "1x1", "flat", "tall"])
+def test_small_tableau_path_at_its_limits_vs_oracle(engine, oracle, m, n, pivots):
+    """The one-workgroup loop heads of small_kernels.hip (R <= 1024, ld <= 2048) forced beyond the
+    size the engine picks them for by itself, at the row limit (R = 1024), on flat / tall / 1 x 1
+    shapes and in ragged legs: status, pivot log, basis and tableau bytes against the oracle."""
+    from lpr_381_group_v22_amd import Tableau
+    T, basis = oracle.gen_dense_tableau(m, n, 11)
+    st, piv, log = oracle.primal_solve(T, basis, pivots if pivots else 100000)
+    tab = Tableau.synthetic(engine, m, n, 11)
+    res = tab.solve(max_pivots=pivots if pivots else 100000, variant=SMALL)
+    assert res.block == 16, "the small-tableau path did not run"
+    assert res.status == st and res.pivots == piv
+    assert tab.pivot_log().tolist() == log.tolist()
+    assert tab.basis().tolist() == basis.tolist()
+    assert tab.read().tobytes() == T.tobytes()
+    tab.destroy()
+    if piv >= 40:  # the same pivots in ragged legs (limits inside a block, resume)
+        tab = Tableau.synthetic(engine, m, n, 11)
+        done = 0
+        for leg in (1, 15, 16, 17, 3):
+            r = tab.solve(max_pivots=leg, variant=SMALL)
+            assert r.status == 5 and r.pivots == leg
+            done += leg
+        T2, b2 = oracle.gen_dense_tableau(m, n, 11)
+        oracle.primal_solve(T2, b2, done)
+        assert tab.read().tobytes() == T2.tobytes() and tab.basis().tolist() == b2.tolist()
+        tab.destroy()
+
+
+def test_small_tableau_path_unbounded_and_degenerate(engine, oracle):
+    """Unbounded exit and tie-saturated ratio tests on the small path."""
+    import lp_cases
+    from lpr_381_group_v22_amd import Tableau
+    for name, (obj, cons, is_max) in [("unbounded", lp_cases.unbounded_lp()),
+                                      ("ties", lp_cases.tie_heavy(33, 20, 3)),
+                                      ("km", lp_cases.klee_minty_bounded(9))]:
+        o, A, ncoef, rel, rhs = lp_cases.flatten(obj, cons)
+        T, basis = oracle.primal_build(o, A, rel, rhs, is_max, ncoef)
+        T0, b0 = T.copy(), basis.copy()
+        st, piv, log = oracle.primal_solve(T, basis, 100000)
+        tab = Tableau.from_array(engine, T0, b0)
+        res = tab.solve(variant=SMALL)
+        assert (res.status, res.pivots) == (st, piv), name
+        assert tab.pivot_log().tolist() == log.tolist(), name
+        assert tab.read().tobytes() == T.tobytes(), name
+        tab.destroy()
