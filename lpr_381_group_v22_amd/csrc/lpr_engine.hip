@@ -442,7 +442,7 @@ static int solve_small(lpr_tableau* t, const lpr_solve_opts& o, lpr_solve_result
 // 0x30tr / 0x40tr / 0x50tr / 0x60tr force a form with tr-row sweep tiles, any other non-zero value
 // (a k_update tile variant, 0x7fff) the one-pivot path.
 static constexpr int kDefaultBlock = 16;
-// (round 2, tools/size_sweep3.sh: with 8-10 us loop heads the two-stream overlap wins from ~80 MB:
+// (round 2, tools/size_sweep.sh: with 8-10 us loop heads the two-stream overlap wins from ~80 MB:
 // 67 MB 99.6 k vs 104.2 k pivots/s for heads-then-sweep, 101 MB 98.7 k vs 92.2 k, 227 MB 93.6 k vs
 // 78.6 k; round 1's crossover was ~300 MB)
 static constexpr size_t kOverlapBytes = (size_t)80 << 20;
@@ -969,7 +969,7 @@ int lpr_primal_solve(lpr_tableau* t, const lpr_solve_opts* opts, lpr_solve_resul
         // 0x40tr: all heads of a block in one persistent launch, then the sweep in place (also the
         // fallback when the second tableau buffer cannot be allocated)
         if (K > 1) {
-            // measured (tools/size_sweep3.sh): up to ~80 MB the heads-then-sweep form is faster
+            // measured (tools/size_sweep.sh): up to ~80 MB the heads-then-sweep form is faster
             // (9.1-9.6 us per pivot), above it hiding the sweep behind the next heads wins
             const size_t tbytes = (size_t)t->rows * t->ld * sizeof(double);
             // above kOverlapBytes the default is the two-stream form of the overlap (0x30tr)

@@ -15,6 +15,8 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out; out=gpurun_out/ab_handoff.jsonl; : > $out
 cp lpr_381_group_v22_amd/_lib/liblpr_engine.so /tmp/lib_wave.so
 cp lpr_381_group_v22_amd/_lib_alt/liblpr_engine.so /tmp/lib_wg.so
+# whatever happens below, the product library is the one left installed
+trap 'cp /tmp/lib_wave.so lpr_381_group_v22_amd/_lib/liblpr_engine.so' EXIT
 for rep in 1 2 3; do
   for which in wave wg; do
     cp /tmp/lib_$which.so lpr_381_group_v22_amd/_lib/liblpr_engine.so
