@@ -361,6 +361,21 @@ int lpr_bb_node_info(lpr_bb* b, const int32_t* ids, int count, double* z_out, do
 int lpr_bb_expand(lpr_bb* b, int count, const int32_t* parent_ids, const int32_t* var,
                   const double* bound, const int32_t* kind, int32_t* child_ids_out,
                   int32_t* status_out, int32_t* pivots_out);
+/* lpr_bb_expand for a caller that also reproduces what the reference PRINTS about each child
+ * (ExecuteBranchAndBound :1086-1208): the pivots of DoDualSimplex ("pivot @ constraint r, column c",
+ * :198 / :276) and every tableau of its list (:292, :341, :388) for DisplayTableau (:623-640) --
+ * the one AddConstraint hands it, then one per pivot; a last tableau dropped by :395-400 is dropped
+ * here too.  Small models only: the tableaux are copied off the device after every pivot step.
+ *   trace_out: (phase 0 dual / 1 primal / 2 "last tableau dropped", row, col) triples of all
+ *     children, child k's are [trace_off_out[k], trace_off_out[k + 1]) (count + 1 offsets);
+ *   tab_out: child k's ntab_out[k] tableaux, each (parent rows + 1) x (parent cols + 1) row-major,
+ *     from tab_off_out[k] (doubles; count + 1 offsets).  Buffers too small: LPR_BAD_ARGUMENT, the
+ *     offsets still say how much is needed. */
+int lpr_bb_expand_traced(lpr_bb* b, int count, const int32_t* parent_ids, const int32_t* var,
+                         const double* bound, const int32_t* kind, int32_t* child_ids_out,
+                         int32_t* status_out, int32_t* pivots_out, int32_t* trace_out,
+                         int64_t trace_cap, int64_t* trace_off_out, double* tab_out, int64_t tab_cap,
+                         int64_t* tab_off_out, int32_t* ntab_out);
 int lpr_bb_release(lpr_bb* b, const int32_t* ids, int count);
 int lpr_bb_node_read(lpr_bb* b, int32_t id, double* out, int32_t* rows, int32_t* cols);
 

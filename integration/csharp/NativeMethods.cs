@@ -141,6 +141,8 @@ namespace LPR_381_Group_V22.Native
         [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_bb_trace_read(IntPtr bb, int[] quads, long cap, out long count);
         // building blocks: batched AddConstraint (:694-803) + DoDualSimplex (:289-468) of many children, node scoring, buffers
         [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_bb_expand(IntPtr bb, int count, int[] parentIds, int[] var, double[] bound, int[] kind, int[] childIds, int[] status, int[] pivots);
+        // the same + what ExecuteBranchAndBound prints about each child: pivot triples and every tableau of DoDualSimplex's list
+        [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_bb_expand_traced(IntPtr bb, int count, int[] parentIds, int[] var, double[] bound, int[] kind, int[] childIds, int[] status, int[] pivots, int[] trace, long traceCap, long[] traceOff, double[] tableaux, long tabCap, long[] tabOff, int[] ntab);
         [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_bb_node_info(IntPtr bb, int[] ids, int count, double[] z, double[] vals);
         [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_bb_node_read(IntPtr bb, int id, double[] tableau, out int rows, out int cols);
         [DllImport(Lib, CallingConvention = CC)] internal static extern int lpr_bb_release(IntPtr bb, int[] ids, int count);

@@ -194,6 +194,9 @@ SIGNATURES = {
     "lpr_bb_trace_read": (C.c_int, [_P, _I32, C.c_int64, _I64]),
     "lpr_bb_node_info": (C.c_int, [_P, _I32, C.c_int, _D, _D]),
     "lpr_bb_expand": (C.c_int, [_P, C.c_int, _I32, _I32, _D, _I32, _I32, _I32, _I32]),
+    "lpr_bb_expand_traced": (C.c_int, [_P, C.c_int, _I32, _I32, _D, _I32, _I32, _I32, _I32, _I32,
+                                       C.c_int64, C.POINTER(C.c_int64), _D, C.c_int64,
+                                       C.POINTER(C.c_int64), _I32]),
     "lpr_bb_release": (C.c_int, [_P, _I32, C.c_int]),
     "lpr_bb_node_read": (C.c_int, [_P, C.c_int32, _D, _I32, _I32]),
     "lpr_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),

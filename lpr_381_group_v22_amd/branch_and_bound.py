@@ -20,6 +20,7 @@ from typing import Callable, List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import _native as N
+from . import table_iteration_formater as fmt
 from .engine import Engine, Tableau, _dptr, _i32ptr
 
 BB_SOLVED, BB_INFEASIBLE, BB_FAILED = 2, 3, 4  # lpr_bb_expand status codes
@@ -121,6 +122,45 @@ class BranchBoundTree:
                                     _i32ptr(child), _i32ptr(st), _i32ptr(piv)), "lpr_bb_expand")
         return child[:k], st[:k], piv[:k]
 
+    def expand_traced(self, parents: Sequence[int], var: Sequence[int], bound: Sequence[float],
+                      kind: Sequence[int], shape: Tuple[int, int]):
+        """lpr_bb_expand_traced: expand() plus, per child, its pivot triples (phase, row, col) and
+        every tableau of DoDualSimplex's list (the one AddConstraint hands it, then one per pivot).
+        ``shape`` = (rows, cols) of the PARENT (all parents of one call have the same shape)."""
+        p = np.ascontiguousarray(parents, dtype=np.int32)
+        v = np.ascontiguousarray(var, dtype=np.int32)
+        b = np.ascontiguousarray(bound, dtype=np.float64)
+        kd = np.ascontiguousarray(kind, dtype=np.int32)
+        k = p.shape[0]
+        child = np.zeros(max(k, 1), dtype=np.int32)
+        st = np.zeros(max(k, 1), dtype=np.int32)
+        piv = np.zeros(max(k, 1), dtype=np.int32)
+        ntab = np.zeros(max(k, 1), dtype=np.int32)
+        rows, cols = shape[0] + 1, shape[1] + 1
+        trace_cap, tab_cap = 4 * (rows + cols) * max(k, 1) + 64, (64 * rows * cols) * max(k, 1)
+        for _ in range(2):  # (a second try with the sizes the first one reported)
+            trace = np.zeros(3 * trace_cap, dtype=np.int32)
+            tabs = np.zeros(tab_cap, dtype=np.float64)
+            toff = (C.c_int64 * (k + 1))()
+            boff = (C.c_int64 * (k + 1))()
+            rc = N.lib.lpr_bb_expand_traced(self._h, k, _i32ptr(p), _i32ptr(v), _dptr(b),
+                                            _i32ptr(kd), _i32ptr(child), _i32ptr(st), _i32ptr(piv),
+                                            _i32ptr(trace), trace_cap, toff, _dptr(tabs), tab_cap,
+                                            boff, _i32ptr(ntab))
+            if rc == N.LPR_BAD_ARGUMENT and (toff[k] > trace_cap or boff[k] > tab_cap):
+                raise N.EngineError(rc, "lpr_bb_expand_traced (a child LP needed more than 64 "
+                                        "tableaux: too large for the narrated path)")
+            N.check(rc, "lpr_bb_expand_traced")
+            break
+        traces, tableaux = [], []
+        for q in range(k):
+            t = trace[3 * toff[q]:3 * toff[q + 1]].reshape(-1, 3)
+            traces.append([tuple(int(x) for x in r) for r in t])
+            tb = tabs[boff[q]:boff[q + 1]].reshape(int(ntab[q]), rows, cols) if ntab[q] else \
+                np.zeros((0, rows, cols))
+            tableaux.append([tb[i].copy() for i in range(int(ntab[q]))])
+        return child[:k], st[:k], piv[:k], traces, tableaux
+
     def release(self, ids: Sequence[int]) -> None:
         a = np.ascontiguousarray(ids, dtype=np.int32)
         if a.shape[0]:
@@ -136,20 +176,158 @@ class BranchBoundTree:
         return out
 
 
+def _g(v: float) -> str:
+    return fmt.dotnet_double_to_string(float(v))
+
+
+def _join(vals) -> str:  # string.Join(", ", List<double>)
+    return ", ".join(_g(v) for v in vals)
+
+
+def execute_branch_and_bound_narrated(tree: "BranchBoundTree", root_shape: Tuple[int, int],
+                                      enable_pruning: bool = False, node_cap: int = 0):
+    """ExecuteBranchAndBound (BranchBoundSimplexSolver.cs:1006-1233) driven from the host over the
+    engine's building blocks, WRITING WHAT THE C# WRITES to the console (captured by Program.cs
+    option 3 into the result file): every node header, the branching lines, "pivot @ constraint r,
+    column c" of every pivot (:198 / :276) and every tableau of every child through DisplayTableau
+    (:623-640).  The numbers -- scores, tableaux, pivots -- come from the device
+    (lpr_bb_node_info, lpr_bb_expand_traced); this function only orders and formats them, and only
+    for textbook-sized models (the adapter's narrate="auto": <= 4 096 tableau entries).  Same search,
+    same answer as lpr_bb_run.  One thing cannot be reproduced: `failed: {e}` (:1147 / :1207) prints
+    a .NET exception with its stack trace; the exception's type and message are printed here, the
+    trace is not.  Returns (x or None, z, processed)."""
+    n = tree.nvars
+    cap = node_cap if node_cap > 0 else 20  # :1038
+    print("Initiating Branch and Bound Algorithm")                       # :1010
+    print("Pruning: Enabled" if enable_pruning else "Pruning: Disabled")  # :1013 / :1017
+    print("-" * 50)                                                       # :1019
+
+    def display(tab: np.ndarray, caption: str) -> None:  # DisplayTableau :623-640
+        if tab is None or tab.size == 0:
+            print(f"{caption} (empty)")
+            return
+        print(fmt.Format(_round4_np(np.asarray(tab, dtype=np.float64)), n, caption))
+
+    optimal_x, optimal_z, optimal_label, optimal_tab = None, -math.inf, None, None
+    branch_count = 0
+    counters = {}
+    # (node id, its rows, cols, depth, label, constraint path, parent label)
+    stack = [(0, root_shape[0], root_shape[1], 0, "0", [], None)]
+    iteration = 0
+    while stack:
+        iteration += 1
+        if iteration > cap:
+            print("Potential infinite loop detected")  # :1040
+            break
+        nid, rows, cols, depth, label, path, parent = stack.pop()
+        branch_count += 1
+        print(f"\n--- Processing branch {label} (Depth {depth}) ---")  # :1049
+        if parent is not None:
+            print(f"Parent branch: {parent}")
+        print(f"Constraint Path: [{', '.join(path)}]")
+        zs, vals = tree.node_info([nid])  # RoundAllTableaux :1047 + GetObjective + ExtractSolution
+        z, sol = float(zs[0]), [float(v) for v in vals[0]]
+        if enable_pruning and optimal_x is not None and z <= optimal_z:  # :1060, :985-1004
+            print(f"branch {label} pruned")
+            tree.release([nid])
+            continue
+        if all(_is_integer(v) for v in sol):  # UpdateOptimalSolution :935-983
+            if z > optimal_z:
+                optimal_z, optimal_x, optimal_label = z, list(sol), label
+                optimal_tab = tree.node_read(nid)
+                print(f"New optimal integer solution found: [{_join(sol)}] with value {_g(z)}")
+            else:
+                print(f"Integer solution found: [{_join(sol)}] with value {_g(z)} (not better "
+                      f"than current optimal)")
+        k, val = choose_branch(sol)  # CreateBranches :859-890
+        if k < 0:
+            print(f"branch {label}: Integer solution [{_join(sol)}] with value {_g(z)}")  # :1074
+            tree.release([nid])
+            continue
+        print(f"Branching on x{k + 1} = {_g(_round4(val))}")  # :868
+        lower = [1.0 if i == k else 0.0 for i in range(n)] + [float(int(math.floor(val))), 0.0]
+        upper = [1.0 if i == k else 0.0 for i in range(n)] + [float(int(math.ceil(val))), 1.0]
+        counters.setdefault(label, 0)
+        child, st, _piv, traces, tabs = tree.expand_traced(
+            [nid, nid], [k, k], [lower[n], upper[n]], [0, 1], (rows, cols))
+        kids = []
+        for side, (name, bnd, star) in enumerate((("Lower", lower, "t"), ("Upper", upper, "x"))):
+            counters[label] += 1
+            if label == "0":
+                child_label = "1" if side == 0 else "2"
+            else:
+                child_label = f"{label}.{counters[label]}"
+            print(f"\n{name} Branch (branch {child_label}): {_join(bnd)} ", end="")  # :1088 / :1155
+            for i in range(n):
+                if bnd[i] == 0:
+                    continue
+                print(f"x{i + 1} " if bnd[i] == 1 else f"{_g(bnd[i])}*{star}{i + 1} ", end="")
+            print("<= " if bnd[-1] == 0 else ">= ", end="")
+            print(f"{_g(bnd[-2])} ", end="")
+            for ph, r, c in traces[side]:  # PerformDualPivot :198 / PerformPrimalPivot :276
+                if ph < 2:
+                    print(f"pivot @ constraint {r}, column {c + 1}")
+            shown = [np.array(t) for t in tabs[side]]
+            if st[side] == BB_FAILED:  # an exception escaped DoDualSimplex (:396-399)
+                print(f"{name} branch (branch {counters[label]}) failed: "
+                      f"System.ArgumentOutOfRangeException: Index was out of range. Must be "
+                      f"non-negative and less than the size of the collection.")
+                continue
+            if st[side] == BB_INFEASIBLE:  # optimalSolution == null :1110 / :1177
+                display(shown[0] if shown else None, f"branch {child_label}: Infeasible tableau")
+                shown = []
+            else:
+                shown = [_round4_np(t) for t in shown]  # RoundAllTableaux :1124 / :1187
+                op = "<=" if side == 0 else ">="
+                desc = f"x{k + 1} {op} {_g(bnd[-2])}"
+                kids.append((int(child[side]), rows + 1, cols + 1, depth + 1, child_label,
+                             path + [desc], label))
+                print(f"{name} branch (branch {child_label}) infeasible")  # (sic) :1130 / :1193
+            for i, t in enumerate(shown[:-1]):
+                display(t, f"branch {child_label} {name} branch Tableau {i + 1}")
+            if shown:
+                display(shown[-1], f"branch {child_label} {name} branch final tableau")
+        for kid in reversed(kids):  # :1210-1213
+            stack.append(kid)
+        tree.release([nid])
+    for item in stack:
+        tree.release([item[0]])
+    print("\n" + "-" * 50)
+    print("BRANCH AND BOUND COMPLETED")
+    print("-" * 50)
+    if optimal_x is not None:
+        display(optimal_tab, f"Optimal solution tableau at branch {optimal_label}")
+        print(f"Optimal branch: {optimal_label}")
+        print(f"Optimal integer solution: [{_join(optimal_x)}]")
+        print(f"Optimal value: {_g(optimal_z)}")
+    else:
+        print("No integer solution found")
+    print(f"Total branchs processed: {branch_count}")
+    return optimal_x, optimal_z, branch_count
+
+
 class BranchAndBoundAdapter:
     """IntegerProgramming/BranchAndBoundAdapter.cs:7-51."""
 
     @staticmethod
     def SolveFromPrimal(primal, enablePruning: bool = False, isMin: bool = False,
-                        node_cap: int = 0) -> Tuple[List[float], float]:
+                        node_cap: int = 0, narrate="auto") -> Tuple[List[float], float]:
         if primal.FinalTableau is None:  # :11-14
             raise RuntimeError("Primal simplex has not been solved yet.")
         # :20  SetNumVars(primal.SolutionVector?.Count ?? InferNumVariables(finalTable))
         nvars = len(primal.SolutionVector) if primal.SolutionVector is not None else \
             max(1, primal.FinalTableau.shape[1] - 1)
         # `isMin` is accepted and ignored, as in the reference (never forwarded, :9,:22)
+        shape = (primal.tableau.rows, primal.tableau.cols)
+        if narrate == "auto":  # the console narration only for models one would read it for
+            narrate = shape[0] * shape[1] <= 4096
         tree = BranchBoundTree.from_tableau(primal.tableau, nvars, max_depth=max(node_cap, 20))
         try:
+            if narrate:
+                x, z, _ = execute_branch_and_bound_narrated(tree, shape, enablePruning, node_cap)
+                if x is None:
+                    return [], -math.inf
+                return [float(v) for v in x], float(z)
             res, x = tree.run(enable_pruning=enablePruning, node_cap=node_cap)
             tree.last_result = res
             BranchAndBoundAdapter.last_tree_records = tree.records()

@@ -230,11 +230,29 @@ static int bb_node_info(lpr_bb* b, const int32_t* ids, int count, double* z_out,
 // AddConstraint (:694-803) + DoDualSimplex (:289-468) + RoundAllTableaux (:1124/:1187) for `count`
 // children, all in one batch.  kind: 0 = lower ("<=", type 0), 1 = upper (">=", type 1).
 // status_out: kBBSolved / kBBInfeasible / kBBFailed; child_ids_out: node id or -1.
+// What lpr_bb_expand_traced keeps of every child besides its outcome: every tableau of
+// DoDualSimplex's list (`tableaux`, :292,:341,:388), compact rows x cols, in order.
+struct BBKeep {
+    std::vector<std::vector<double>> tabs;  // [child] -> concatenated tableaux
+    std::vector<int> ntab;                  // [child] -> how many
+};
+
+static int bb_keep_copy(lpr_bb* b, const BBSlot& s, std::vector<double>* dst) {
+    const size_t n = (size_t)s.rows * s.cols;
+    const size_t at = dst->size();
+    dst->resize(at + n);
+    LPR_HIP(hipMemcpy2DAsync(dst->data() + at, (size_t)s.cols * sizeof(double), s.cur,
+                             (size_t)b->ld * sizeof(double), (size_t)s.cols * sizeof(double),
+                             s.rows, hipMemcpyDeviceToHost, b->eng->stream));
+    LPR_HIP(hipStreamSynchronize(b->eng->stream));
+    return LPR_OK_OPTIMAL;
+}
+
 static int bb_expand(lpr_bb* b, int count, const int32_t* parent_ids, const int32_t* var,
                      const double* bound, const int32_t* kind, int32_t* child_ids_out,
                      int32_t* status_out, int32_t* pivots_out,
                      std::vector<int32_t>* trace_out /* triples per child, flattened */,
-                     std::vector<int32_t>* trace_off) {
+                     std::vector<int32_t>* trace_off, BBKeep* keep = nullptr) {
     if (count <= 0) return LPR_OK_OPTIMAL;
     int rc = bb_ensure_slots(b, count);
     if (rc != LPR_OK_OPTIMAL) return rc;
@@ -290,6 +308,18 @@ static int bb_expand(lpr_bb* b, int count, const int32_t* parent_ids, const int3
     for (int k = 0; k < count; ++k)
         side = side && b->nodes[parent_ids[k]].side && !b->nodes[parent_ids[k]].big;
     bb_launch_add_constraint(b, count, nparents, rows_max, cols_max, side);
+    std::vector<int> kept_pivots;
+    if (keep) {  // tableaux[0]: what AddConstraint hands to DoDualSimplex (:1105,:1172)
+        keep->tabs.assign(count, {});
+        keep->ntab.assign(count, 0);
+        kept_pivots.assign(count, 0);
+        LPR_HIP(hipGetLastError());
+        for (int k = 0; k < count; ++k) {
+            rc = bb_keep_copy(b, b->h_slots[k], &keep->tabs[k]);
+            if (rc != LPR_OK_OPTIMAL) return rc;
+            keep->ntab[k] = 1;
+        }
+    }
 
     // DoDualSimplex: pivot steps until every child has left the running states
     // Pivot steps queued between polls of the running counter.  A poll idles the device ~50 us; a
@@ -298,6 +328,7 @@ static int bb_expand(lpr_bb* b, int count, const int32_t* parent_ids, const int3
     // the level before (running[1] of that batch), so the first batch is sized by it; without a
     // history 4, then doubling up to 32.
     int poll = b->last_steps > 4 ? b->last_steps : 4;
+    if (keep) poll = 1;  // every tableau is copied off the device: one step at a time
     int queued = 0;
     int64_t guard = 0;
     for (;;) {
@@ -310,6 +341,27 @@ static int bb_expand(lpr_bb* b, int count, const int32_t* parent_ids, const int3
         LPR_HIP(hipStreamSynchronize(st));
         b->prof.polls += 1;
         b->prof.steps += poll;
+        if (keep) {  // the list grows by the tableau of a pivot, shrinks by a dropped one (:395-400)
+            LPR_HIP(hipMemcpyAsync(b->h_slots, b->d_slots, (size_t)count * sizeof(BBSlot),
+                                   hipMemcpyDeviceToHost, st));
+            LPR_HIP(hipStreamSynchronize(st));
+            for (int k = 0; k < count; ++k) {
+                const BBSlot& s = b->h_slots[k];
+                const size_t n = (size_t)s.rows * s.cols;
+                if (s.pivots > kept_pivots[k]) {
+                    rc = bb_keep_copy(b, s, &keep->tabs[k]);
+                    if (rc != LPR_OK_OPTIMAL) return rc;
+                    keep->ntab[k] += 1;
+                } else if (s.pivots < kept_pivots[k] && keep->ntab[k] > 0) {
+                    keep->tabs[k].resize(keep->tabs[k].size() - n);
+                    keep->ntab[k] -= 1;
+                }
+                kept_pivots[k] = s.pivots;
+            }
+            poll = 1;
+            if (b->h_running[0] <= 0) break;
+            continue;
+        }
         if (b->h_running[0] <= 0) break;
         poll = (queued <= 4 && b->last_steps <= 4) ? 8 : 4;  // (then in fours: the tail is short)
         if (b->last_steps <= 4 && queued >= 12) poll = queued < 32 ? queued : 32;
@@ -514,6 +566,49 @@ int lpr_bb_expand(lpr_bb* b, int count, const int32_t* parent_ids, const int32_t
     LPR_HIP(hipSetDevice(b->eng->device));
     return bb_expand(b, count, parent_ids, var, bound, kind, child_ids_out, status_out,
                      pivots_out, nullptr, nullptr);
+}
+
+int lpr_bb_expand_traced(lpr_bb* b, int count, const int32_t* parent_ids, const int32_t* var,
+                         const double* bound, const int32_t* kind, int32_t* child_ids_out,
+                         int32_t* status_out, int32_t* pivots_out, int32_t* trace_out,
+                         int64_t trace_cap, int64_t* trace_off_out, double* tab_out, int64_t tab_cap,
+                         int64_t* tab_off_out, int32_t* ntab_out) {
+    LPR_LIVE_BB(b);
+    if (count < 0 || (count > 0 && (!parent_ids || !var || !bound || !kind || !child_ids_out ||
+                                    !status_out || !trace_off_out || !tab_off_out || !ntab_out)) ||
+        trace_cap < 0 || tab_cap < 0)
+        return LPR_BAD_ARGUMENT;
+    for (int k = 0; k < count; ++k)
+        if (var[k] < 0 || var[k] >= b->nvars) {
+            set_error("lpr_bb_expand_traced: branching variable %d out of range", var[k]);
+            return LPR_BAD_ARGUMENT;
+        }
+    LPR_HIP(hipSetDevice(b->eng->device));
+    std::vector<int32_t> tr, off;
+    BBKeep keep;
+    int rc = bb_expand(b, count, parent_ids, var, bound, kind, child_ids_out, status_out,
+                       pivots_out, &tr, &off, &keep);
+    if (rc != LPR_OK_OPTIMAL) return rc;
+    int64_t tpos = 0;
+    for (int k = 0; k < count; ++k) {
+        trace_off_out[k] = off[k] / 3;
+        const size_t n = keep.tabs[k].size();
+        tab_off_out[k] = tpos;
+        ntab_out[k] = keep.ntab[k];
+        if (tab_out && tpos + (int64_t)n <= tab_cap)
+            std::memcpy(tab_out + tpos, keep.tabs[k].data(), n * sizeof(double));
+        tpos += (int64_t)n;
+    }
+    trace_off_out[count] = off[count] / 3;
+    tab_off_out[count] = tpos;
+    const int64_t nt = (int64_t)tr.size() / 3;
+    if (trace_out) std::memcpy(trace_out, tr.data(), (size_t)(nt < trace_cap ? nt : trace_cap) * 3 * sizeof(int32_t));
+    if ((tab_out && tpos > tab_cap) || (trace_out && nt > trace_cap)) {
+        set_error("lpr_bb_expand_traced: output buffers too small (%lld tableau doubles, %lld pivot "
+                  "triples needed)", (long long)tpos, (long long)nt);
+        return LPR_BAD_ARGUMENT;
+    }
+    return LPR_OK_OPTIMAL;
 }
 
 int lpr_bb_release(lpr_bb* b, const int32_t* ids, int count) {

@@ -29,18 +29,7 @@ from .revised_primal_simplex_solver import RevisedPrimalSimplexSolver
 NL = fmt.NEWLINE
 
 
-def dotnet_double_to_string(v: float) -> str:
-    """double.ToString() on .NET Framework ("G", 15 significant digits)."""
-    if v != v:
-        return "NaN"
-    if v in (float("inf"), float("-inf")):
-        return "Infinity" if v > 0 else "-Infinity"
-    s = format(v, ".15g")
-    if "e" in s:
-        mant, exp = s.split("e")
-        sign = "+" if int(exp) >= 0 else "-"
-        s = f"{mant}E{sign}{abs(int(exp)):02d}"
-    return "0" if s in ("-0", "0") else s
+dotnet_double_to_string = fmt.dotnet_double_to_string  # double.ToString() ("G")
 
 
 def _format_coeff(c: float) -> str:  # CanonicalFormConverter.cs:95-98

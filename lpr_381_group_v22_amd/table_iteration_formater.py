@@ -46,6 +46,20 @@ def F6(v: float) -> str:
     return format_fixed(v, 6)
 
 
+def dotnet_double_to_string(v: float) -> str:
+    """double.ToString() on .NET Framework ("G", 15 significant digits)."""
+    if v != v:
+        return "NaN"
+    if v in (float("inf"), float("-inf")):
+        return "Infinity" if v > 0 else "-Infinity"
+    s = format(v, ".15g")
+    if "e" in s:
+        mant, exp = s.split("e")
+        sign = "+" if int(exp) >= 0 else "-"
+        s = f"{mant}E{sign}{abs(int(exp)):02d}"
+    return "0" if s in ("-0", "0") else s
+
+
 def dotnet_round_half_even(x: float) -> float:
     """Math.Round(double) on .NET Framework (classlibnative COMDouble::Round)."""
     if math.isnan(x) or math.isinf(x):

@@ -121,19 +121,24 @@ def test_option1_result_file_byte_for_byte(engine, tmp_path, name):
         assert ref.status == "optimal" and b"Z* = 2\r\n" in got
 
 
-def test_option3_result_file_parts_that_do_not_need_the_narration(engine, tmp_path):
+def test_option3_result_file_byte_for_byte(engine, tmp_path):
     """Option 3 (Program.cs:356-415) writes ONE captured console text through WriteSnapshotsOnly
-    (OutputFileWrite.cs:83-119).  Compared byte for byte with the independent restatement: the
-    file's frame (header, "=== Solver Log ===", final results through N3) and the captured text up
-    to the end of the primal solve (banner, DisplayCanonicalForm, every Before / After pivot table,
-    the summary).  NOT mirrored and not compared: the Branch & Bound narration in between
-    (BranchBoundSimplexSolver.cs: 50 Console.Write sites incl. every intermediate tableau of every
-    child and .NET exception dumps) -- control-plane text, DESIGN.md section 9."""
+    (OutputFileWrite.cs:83-119): the banner, DisplayCanonicalForm, the primal solve's Before / After
+    pivot tables, then everything ExecuteBranchAndBound (BranchBoundSimplexSolver.cs:1006-1233)
+    writes -- node headers, branching lines, "pivot @ constraint r, column c" of every pivot, every
+    tableau of every child through DisplayTableau -- and the result block.  The whole file, byte for
+    byte (timestamp masked), against the independent restatement: tests/ref_py_bb.py (the search),
+    tests/ref_py_bb_text.py (what it prints), tests/ref_py_text.py (number / table formatting, the
+    file).  The numbers of the product side come from the device (lpr_bb_node_info,
+    lpr_bb_expand_traced).  No branch of this model fails, so the one thing that cannot be
+    reproduced (`failed: {e}`, a .NET stack trace) does not occur."""
     import lpr_381_group_v22_amd as pkg
     from lpr_381_group_v22_amd.program import run_option
     from ref_py import parse_model_text, program_option1_constraints
+    from ref_py_bb_text import NarratedBranchAndBound
     from ref_py_text import (CRLF, PyPrimalText, mask_timestamp, py_canonical_form_console,
-                             py_write_snapshots_only)
+                             py_double_to_string, py_write_snapshots_only)
+    from ref_py import py_n3
     path = os.path.join(HERE, "golden", "TextFile.txt")
     p = pkg.InputFileParser()
     p.ReadInputFile(path)
@@ -143,15 +148,56 @@ def test_option3_result_file_parts_that_do_not_need_the_narration(engine, tmp_pa
     ptype, obj, cons, signs = parse_model_text(open(path).read())
     ref = PyPrimalText(obj, program_option1_constraints(len(obj), cons), True)
     _snaps, console = ref.solve_text()
-    head = ("Solving with Branch and Bound Simplex Algorithm..." + CRLF
-            + py_canonical_form_console(ptype, obj, cons, signs) + console)
-    tail = ("\n=== Branch & Bound Result ===" + CRLF + "Z* = 15" + CRLF  # Program.cs:391-394
-            + "".join(f"x{i + 1} = {v}" + CRLF for i, v in enumerate([0, 1, 1, 1, 0, 1])))
-    frame = py_write_snapshots_only("Branch and Bound Simplex Algorithm", [head + "<NARRATION>" + tail],
-                                    r["z"], r["x"])
-    pre, post = frame.split(b"<NARRATION>")
-    assert got.startswith(pre), "frame / canonical form / primal console text differ"
-    assert got.endswith(post), "result block / final results differ"
+    bb = NarratedBranchAndBound(len(obj))
+    res = bb.ExecuteNarrated(ref.t)
+    assert "failed:" not in res["text"] and res["processed"] == 20
+    x_bb = res["x"] if res["x"] is not None else []
+
+    def f0(v):  # {v:0.###}
+        return py_n3(v) if abs(v) >= 1e-12 or v == 0 else py_n3(v)
+
+    text = ("Solving with Branch and Bound Simplex Algorithm..." + CRLF
+            + py_canonical_form_console(ptype, obj, cons, signs) + console + res["text"]
+            + "\n=== Branch & Bound Result ===" + CRLF + "Z* = " + f0(res["z"]) + CRLF
+            + "".join(f"x{i + 1} = {f0(v)}" + CRLF for i, v in enumerate(x_bb)))
+    want = py_write_snapshots_only("Branch and Bound Simplex Algorithm", [text], res["z"], x_bb)
+    assert r["z"] == res["z"] and r["x"] == x_bb
+    if got != want:  # show where the two texts part
+        k = next(i for i in range(min(len(got), len(want))) if got[i] != want[i])
+        raise AssertionError(f"first difference at byte {k}: got {got[max(0, k - 120):k + 80]!r} "
+                             f"want {want[max(0, k - 120):k + 80]!r}")
+    assert b"Total branchs processed: 20" in got and b"Optimal branch: 1.1" in got
+
+
+@pytest.mark.parametrize("name", ["binary_4v1c_s0", "frac_4v2c_s10", "binary_8v3c_s3",
+                                  "binary_6v2c_s2"])
+def test_narrated_branch_and_bound_equals_the_batched_one_and_the_restatement(engine, oracle,
+                                                                            name, capsys):
+    """The host-driven, narrating form of ExecuteBranchAndBound (lpr_bb_node_info +
+    lpr_bb_expand_traced) against lpr_bb_run (same x, z) and against the restated console text,
+    on instances with infeasible children, primal-phase pivots and a dropped last tableau."""
+    import bb_cases
+    import lp_cases
+    import lpr_381_group_v22_amd as pkg
+    from ref_py import PyPrimal
+    from ref_py_bb_text import NarratedBranchAndBound
+    from ref_py_text import CRLF
+    obj, cons = dict(bb_cases.all_bb_cases())[name]
+    s = pkg.PrimalSimplexSolver(obj, [pkg.Constraint(list(c.Coefficients), c.Relation, c.RHS)
+                                      for c in cons], True, engine=engine, snapshots="none")
+    s.Solve()
+    x0, z0 = pkg.BranchAndBoundAdapter.SolveFromPrimal(s, narrate=False)
+    capsys.readouterr()
+    x1, z1 = pkg.BranchAndBoundAdapter.SolveFromPrimal(s, narrate=True)
+    text = capsys.readouterr().out
+    assert x1 == x0 and (z1 == z0 or (z1 != z1 and z0 != z0))
+    p = PyPrimal(obj, cons, True)
+    p.solve()
+    bb = NarratedBranchAndBound(len(obj))
+    res = bb.ExecuteNarrated(p.t)
+    assert (res["x"] or []) == x1
+    # print() ends lines with "\n" where Console.WriteLine writes Environment.NewLine
+    assert text.replace(CRLF, "\n") == res["text"].replace(CRLF, "\n")
 
 
 def test_option2_result_file_byte_for_byte(engine, tmp_path):
