@@ -132,3 +132,25 @@ def test_golden_fixture(oracle):
         assert [[rec["parent"], rec["kind"], rec["var"], rec["status"], bits(rec["z"])]
                 for rec in r["records"]] == g["records"], key
         assert [list(t) for t in r["trace"]] == g["trace"], key
+
+
+def test_narrated_restatement_runs_the_same_search():
+    """tests/ref_py_bb_text.py (what ExecuteBranchAndBound prints) re-walks the search of
+    tests/ref_py_bb.py with labels and constraint paths: same x, z and node count on every case,
+    and a text whose pivot lines are the pivots of the trace."""
+    import bb_cases
+    from ref_py import PyPrimal
+    from ref_py_bb import BranchAndBound
+    from ref_py_bb_text import NarratedBranchAndBound
+    for name, (obj, cons) in bb_cases.all_bb_cases():
+        p = PyPrimal(obj, cons, True)
+        if p.solve() != "optimal":
+            continue
+        a = BranchAndBound(len(obj))
+        ra = a.Execute([list(r) for r in p.t])
+        b = NarratedBranchAndBound(len(obj))
+        rb = b.ExecuteNarrated([list(r) for r in p.t])
+        assert ra["x"] == rb["x"] and ra["processed"] == rb["processed"], name
+        assert (ra["z"] == rb["z"]) or (ra["z"] != ra["z"] and rb["z"] != rb["z"]), name
+        assert rb["text"].count("pivot @ constraint") == sum(1 for t in a.trace if t[1] < 2), name
+        assert f"Total branchs processed: {ra['processed']}\r\n" in rb["text"], name
