@@ -64,6 +64,7 @@ struct lpr_bb {
     std::vector<Node> nodes;          // node id -> buffer
     std::vector<double*> free_bufs;   // recycled device buffers
     std::vector<double*> all_bufs;    // everything ever allocated (freed at destroy)
+    size_t pool_bytes = 0;            // ... and how much that is
     // batch scratch (grown on demand)
     int slot_cap = 0;
     lpr::BBSlot* d_slots = nullptr;

@@ -101,10 +101,15 @@ static int bb_alloc_buf(lpr_bb* b, double** out) {
     } acc{b, t0};
     // grow the pool by a slab of buffers at a time (hundreds of children per level: one
     // hipMalloc each would cost more than solving them)
+    // ... and every slab as large as everything allocated before it (128 MB, 128, 256, 512 MB, ...):
+    // a tree that doubles per level then needs one hipMalloc per level, not one per 128 MB
+    // (51 of them cost 0.84 of the 15.7 ms of the bench tree)
     const size_t bytes = b->buf_elems * sizeof(double);
-    size_t per = ((size_t)128 << 20) / bytes;
+    size_t slab = (size_t)128 << 20;
+    if (b->pool_bytes > slab) slab = b->pool_bytes;
+    if (slab > ((size_t)8 << 30)) slab = (size_t)8 << 30;
+    size_t per = slab / bytes;
     if (per < 4) per = 4;
-    if (per > 512) per = 512;
     double* p = nullptr;
     hipError_t err = hipMalloc(&p, per * bytes);
     if (err != hipSuccess) {
@@ -117,6 +122,7 @@ static int bb_alloc_buf(lpr_bb* b, double** out) {
         return err == hipErrorOutOfMemory ? LPR_OUT_OF_MEMORY : LPR_DEVICE_ERROR;
     }
     b->all_bufs.push_back(p);  // slab base: what hipFree gets at destroy
+    b->pool_bytes += per * bytes;
     for (size_t k = 1; k < per; ++k) b->free_bufs.push_back(p + k * b->buf_elems);
     *out = p;
     return LPR_OK_OPTIMAL;
@@ -327,7 +333,10 @@ static int bb_expand(lpr_bb* b, int count, const int32_t* parent_ids, const int3
     // (10-40 us at a wide level).  The children of one level need about as many steps as those of
     // the level before (running[1] of that batch), so the first batch is sized by it; without a
     // history 4, then doubling up to 32.
-    int poll = b->last_steps > 4 ? b->last_steps : 4;
+    // (round 3: a step queued behind the end of a batch is two near-empty launches, ~10 us, since
+    // k_bb_update takes 8 listed rows per workgroup instead of one workgroup per 4 rows of every
+    // child; a poll costs the device ~70 us of idling: the first batch is sized generously)
+    int poll = b->last_steps > 4 ? b->last_steps + 2 : 6;
     if (keep) poll = 1;  // every tableau is copied off the device: one step at a time
     int queued = 0;
     int64_t guard = 0;
