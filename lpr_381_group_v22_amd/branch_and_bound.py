@@ -245,8 +245,8 @@ def execute_branch_and_bound_narrated(tree: "BranchBoundTree", root_shape: Tuple
             tree.release([nid])
             continue
         print(f"Branching on x{k + 1} = {_g(_round4(val))}")  # :868
-        lower = [1.0 if i == k else 0.0 for i in range(n)] + [float(int(math.floor(val))), 0.0]
-        upper = [1.0 if i == k else 0.0 for i in range(n)] + [float(int(math.ceil(val))), 1.0]
+        lower = [1.0 if i == k else 0.0 for i in range(n)] + [float(dotnet_int32(math.floor(val))), 0.0]
+        upper = [1.0 if i == k else 0.0 for i in range(n)] + [float(dotnet_int32(math.ceil(val))), 1.0]
         counters.setdefault(label, 0)
         child, st, _piv, traces, tabs = tree.expand_traced(
             [nid, nid], [k, k], [lower[n], upper[n]], [0, 1], (rows, cols))
@@ -340,6 +340,14 @@ class BranchAndBoundAdapter:
 
 # ---------------------------------------------------------------------------------------------
 # .NET Framework rounding on the host (tree decisions work on n values per node)
+def dotnet_int32(x: float) -> int:
+    """`(int)d` of the C# (:870-871) as .NET Framework 4.7.2's x64 JIT compiles it (cvttsd2si):
+    outside int's range, or NaN, the result is 0x80000000 (LP values of 1e15 do occur)."""
+    if not (-2147483649.0 < x < 2147483648.0):
+        return -2147483648
+    return int(x)
+
+
 def _round_int(x: float) -> float:
     if x != x or x in (math.inf, -math.inf):
         return x
@@ -497,7 +505,7 @@ def solve_level_synchronous(evaluator, nvars: int, *, rank: int = 0, world: int 
                     for side, bnd in ((0, math.floor(val)), (1, math.ceil(val))):
                         parents.append(nid)
                         var.append(k)
-                        bound.append(float(int(bnd)))
+                        bound.append(float(dotnet_int32(bnd)))
                         kind.append(side)
                         paths.append(path + (side,))
             if parents:

@@ -45,6 +45,12 @@ static double dn_round_int(double x) {  // Math.Round(double), COMDouble::Round
     if (f == t && std::fmod(t, 2.0) != 0) f -= 1.0;
     return std::copysign(f, x);
 }
+// `(int)d` of the C# (:870-871) as the x64 JIT of .NET Framework 4.7.2 compiles it (cvttsd2si): a
+// value outside int's range, or NaN, gives 0x80000000.  Spelt out: in C++ that cast is undefined.
+static int dn_to_int32(double x) {
+    if (!(x > -2147483649.0 && x < 2147483648.0)) return INT32_MIN;
+    return (int)x;
+}
 static double dn_round4(double x) {  // Math.Round(double, 4)
     if (std::fabs(x) < 1e16) {
         x = x * 10000.0;
@@ -731,8 +737,8 @@ int lpr_bb_run(lpr_bb* b, const lpr_bb_opts* opts, double* x, lpr_bb_result* res
             bb_release_node(b, nid);
             continue;
         }
-        const int upperInt = (int)std::ceil(bestValue);   // :870-871
-        const int lowerInt = (int)std::floor(bestValue);
+        const int upperInt = dn_to_int32(std::ceil(bestValue));   // :870-871
+        const int lowerInt = dn_to_int32(std::floor(bestValue));
 
         // both children in one batch: lower (<= floor, :1083-1148), upper (>= ceil, :1150-1208)
         int32_t parents[2] = {nid, nid};
@@ -924,8 +930,8 @@ int lpr_bb_solve_level_sync(lpr_bb* b, lpr_comm* comm, const lpr_bb_sync_opts* o
                 for (int side = 0; side < 2; ++side) {  // CreateBranches :859-890
                     parents.push_back(frontier[q].node);
                     var.push_back(bestVar);
-                    bound.push_back((double)(int)(side == 0 ? std::floor(bestValue)
-                                                            : std::ceil(bestValue)));
+                    bound.push_back((double)dn_to_int32(side == 0 ? std::floor(bestValue)
+                                                                  : std::ceil(bestValue)));
                     kind.push_back(side);
                     Path p = frontier[q].path;
                     if (side) p.bits |= (uint64_t)1 << p.len;

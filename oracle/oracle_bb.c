@@ -325,6 +325,13 @@ static int do_dual_simplex(Tab start, Tab* last, int* npiv, int node, PivTrace* 
 
 #define BB_EPS 1e-6 /* :493 */
 
+/* `(int)d` (:870-871) as .NET Framework 4.7.2's x64 JIT compiles it (cvttsd2si): out of int's range,
+ * or NaN, gives 0x80000000.  Spelt out because the C cast is undefined there. */
+static int orc_to_int32(double x) {
+    if (!(x > -2147483649.0 && x < 2147483648.0)) return (-2147483647 - 1);
+    return (int)x;
+}
+
 static int is_integer(double v) { /* :595-599 */
     double r = orc_round4(v);
     return fabs(r - orc_round_int(r)) <= BB_EPS;
@@ -548,8 +555,8 @@ int orc_bb_solve(const double* final_tableau, int rows, int cols, int nvars, int
             tab_free(&node.tab);
             continue;
         }
-        int upperInt = (int)ceil(bestValue);
-        int lowerInt = (int)floor(bestValue);
+        int upperInt = orc_to_int32(ceil(bestValue));
+        int lowerInt = orc_to_int32(floor(bestValue));
 
         StackNode kids[2];
         int nk = 0;

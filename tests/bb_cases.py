@@ -35,12 +35,23 @@ def fractional_program(n: int, mcons: int, seed: int):
     return c.tolist(), program_option1_constraints(n, cons)
 
 
+def huge_relaxation_value():
+    """An instance (found by tools/fuzz_bb_gpu.py, seed 2955) where a child's relaxation puts
+    1.1e15 into a decision variable: `(int)Math.Floor(v)` (:870-871) is then out of int's range and
+    the bound of BOTH children becomes int.MinValue (x64 cvttsd2si)."""
+    rng = np.random.RandomState(2955)
+    n, mc = int(rng.randint(3, 14)), int(rng.randint(1, 6))
+    gen = random_binary_program if rng.randint(0, 2) else fractional_program
+    return gen(n, mc, int(rng.randint(0, 1 << 30)))
+
+
 def all_bb_cases():
     cases = [("knapsack_sample", knapsack_sample())]
     for (n, mc, seed) in [(4, 1, 0), (5, 2, 1), (6, 2, 2), (8, 3, 3), (10, 2, 4), (7, 4, 5)]:
         cases.append((f"binary_{n}v{mc}c_s{seed}", random_binary_program(n, mc, seed)))
     for (n, mc, seed) in [(4, 2, 10), (6, 3, 11), (9, 2, 12)]:
         cases.append((f"frac_{n}v{mc}c_s{seed}", fractional_program(n, mc, seed)))
+    cases.append(("huge_relaxation_value", huge_relaxation_value()))
     return cases
 
 

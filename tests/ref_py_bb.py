@@ -12,6 +12,11 @@ INF = math.inf
 
 
 # ---- .NET Framework rounding -----------------------------------------------------------------
+def to_int32(x: float) -> int:
+    """`(int)d` (:870-871) under .NET Framework 4.7.2 x64 (cvttsd2si): 0x80000000 out of range."""
+    return int(x) if -2147483649.0 < x < 2147483648.0 else -2147483648
+
+
 def round_int(x: float) -> float:
     """Math.Round(double) (COMDouble::Round)."""
     if x != x or x in (INF, -INF):
@@ -301,8 +306,8 @@ class BranchAndBound:
                         bestValue = v
             if best == -1:
                 continue
-            upperInt = int(math.ceil(bestValue))
-            lowerInt = int(math.floor(bestValue))
+            upperInt = to_int32(math.ceil(bestValue))
+            lowerInt = to_int32(math.floor(bestValue))
             kids = []
             for side, (bound, typ) in enumerate(((lowerInt, 0), (upperInt, 1))):
                 con = [1.0 if i == best else 0.0 for i in range(self.nvars)] + [float(bound),

@@ -12,7 +12,7 @@ from __future__ import annotations
 import math
 from typing import List, Optional
 
-from ref_py_bb import INF, BranchAndBound
+from ref_py_bb import INF, BranchAndBound, to_int32
 from ref_py_text import CRLF, py_double_to_string, py_format_table
 
 
@@ -92,9 +92,9 @@ class NarratedBranchAndBound(BranchAndBound):
             self.wl(f"Branching on x{best + 1} = {_g(_r4(bestValue))}")           # :868
             n = self.nvars
             lowerBound = [1.0 if i == best else 0.0 for i in range(n)] + \
-                [float(int(math.floor(bestValue))), 0.0]
+                [float(to_int32(math.floor(bestValue))), 0.0]
             upperBound = [1.0 if i == best else 0.0 for i in range(n)] + \
-                [float(int(math.ceil(bestValue))), 1.0]
+                [float(to_int32(math.ceil(bestValue))), 1.0]
             childCounters.setdefault(label, 0)
             kids = []
             for side, (name, bnd, star) in enumerate((("Lower", lowerBound, "t"),

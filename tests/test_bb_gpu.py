@@ -196,6 +196,35 @@ def test_level_sync_in_the_library_equals_the_python_mirror_and_the_dfs(engine, 
     assert done >= 3
 
 
+def test_level_sync_bound_outside_int_range(engine, oracle):
+    """`(int)Math.Floor(value)` (:870-871) of a relaxation value of 1.1e15: C ABI driver, Python
+    mirror over the GPU tree and Python mirror over the oracle's evaluator take the same children
+    (bound int.MinValue on both sides) and count the same pivots at every depth limit."""
+    from oracle_evaluator import OracleEvaluator
+    from lpr_381_group_v22_amd import (BranchBoundTree, solve_level_sync_native,
+                                       solve_level_synchronous)
+    from lpr_381_group_v22_amd.branch_and_bound import dotnet_int32
+    assert dotnet_int32(1125965583789882.0) == -2147483648 == dotnet_int32(float("nan"))
+    assert dotnet_int32(-2147483648.9) == -2147483648 and dotnet_int32(2147483647.9) == 2147483647
+    assert dotnet_int32(-3.0) == -3
+    obj, cons = bb_cases.huge_relaxation_value()
+    st, T, n = bb_cases.primal_final_tableau(oracle, obj, cons)
+    assert st == 0
+    for levels in (2, 3, 4):
+        a = BranchBoundTree.from_array(engine, T, n, max_depth=24)
+        nat = solve_level_sync_native(a, max_levels=levels)
+        a.destroy()
+        b = BranchBoundTree.from_array(engine, T, n, max_depth=24)
+        py = solve_level_synchronous(b, n, max_levels=levels)
+        b.destroy()
+        orc = solve_level_synchronous(OracleEvaluator(oracle, T, n), n, max_levels=levels)
+        assert nat["pivots"] == py["pivots"] == orc["pivots"], levels
+        assert nat["processed"] == py["processed"] == orc["processed"], levels
+        assert nat["found"] == py["found"] == orc["found"], levels
+        if nat["found"]:
+            assert bits(nat["z"]) == bits(py["z"]) == bits(orc["z"]), levels
+
+
 def test_rccl_communicator_of_one_rank(engine, oracle):
     """lpr_comm_init -> ncclCommInitRank inside the library (world size 1: the pool gives one GPU);
     the levels' all-reduce(MAX) and the final all-gather really go through RCCL: one all-reduce per

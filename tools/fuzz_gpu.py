@@ -50,8 +50,8 @@ while time.time() < t_end:
     total = 0
     for leg in range(5):
         limit = int(rng.choice([1, 3, 16, 17, 33, 50, 0]))
-        variant = int(rng.choice([0, 0, SEQ, OV, OV2, INPLACE]))
-        block = 0 if variant == 0 else int(rng.randint(2, (8 if variant == INPLACE else 16) + 1))
+        variant = int(rng.choice([0, 0, SEQ, OV, OV2, INPLACE, 0x2000]))  # 0x2000: small_kernels.hip
+        block = 0 if variant in (0, 0x2000) else int(rng.randint(2, (8 if variant == INPLACE else 16) + 1))
         cap = limit if limit else (400 if shape == 4 else 100000)
         st, piv, log = oracle.primal_solve(T, basis, cap)
         res = tab.solve(max_pivots=cap, block=block, variant=variant)
