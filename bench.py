@@ -87,10 +87,14 @@ def _pmc_kernel_traffic(workload: str) -> dict:
         try:
             with open(path) as f:
                 d = json.load(f)
+            short = lambda k: k.replace("void ", "").split("<")[0].split("::")[-1]  # noqa: E731
             out = {"source": os.path.relpath(path, ROOT),
-                   "kernels": {k.replace("void ", "").split("<")[0].split("::")[-1]:
-                               int(v["hbm_side_bytes"]) for k, v in d["kernels"].items()
-                               if "lpr::" in k}}
+                   "kernels": {short(k): int(v["hbm_side_bytes"]) for k, v in d["kernels"].items()
+                               if "lpr::" in k},
+                   # every dispatch of the run summed (absent in summaries of earlier rounds)
+                   "totals": {short(k): int(v["hbm_side_bytes_all_dispatches"])
+                              for k, v in d["kernels"].items()
+                              if "lpr::" in k and "hbm_side_bytes_all_dispatches" in v}}
         except (OSError, ValueError, KeyError):
             continue
     return out
@@ -521,14 +525,19 @@ def run_bb(args, D: Dist):
                        "collective": "1 ncclAllReduce(MAX, 24 B)/level issued by "
                                      "lpr_bb_solve_level_sync" if comm else "none (one rank)",
                        "parallelism": f"subtree{D.world}"},
-            "roofline": {"bound": "hbm", "kernel": "k_bb_update (batched out-of-place pivot of "
-                                                   "all live children)",
+            "roofline": {"bound": "hbm", "kernel": "whole job (k_bb_select + k_bb_update: batched "
+                                                   "in-place pivots of all live children; "
+                                                   "k_bb_child_init, k_bb_eliminate, k_bb_finish)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                         # PMC: bytes of the median working k_bb_update dispatch (one pivot step of
-                         # every live child of a batch); all kernels in pmc_traffic_per_dispatch
-                         "traffic": (pmc.get("kernels") or {}).get("k_bb_update"),
+                         # PMC: HBM-side bytes of EVERY dispatch of the job's kernels summed (the
+                         # whole-job counterpart of `achieved`'s algorithmic bytes); per kernel in
+                         # pmc_traffic_job, the widest dispatches' median in pmc_traffic_per_dispatch
+                         "traffic": (sum(v for k, v in pmc["totals"].items() if k.startswith("k_bb_"))
+                                     if pmc.get("totals") else None),
                          "traffic_source": pmc.get("source"),
+                         "algorithmic_bytes_job": int(res["pivots"] * bytes_per_pivot),
+                         "pmc_traffic_job": pmc.get("totals") or None,
                          "pmc_traffic_per_dispatch": pmc.get("kernels"),
                          "bytes_per_pivot": int(bytes_per_pivot),
                          "note": "whole-job form: ALGORITHMIC bytes of all sub-problem pivots (2*8*R*C "

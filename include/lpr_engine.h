@@ -124,15 +124,19 @@ typedef struct lpr_solve_opts {
                               bits: path + sweep tile (0x30tr two-stream overlap, 0x40tr heads then
                               in-place sweep, 0x50tr one-launch overlap, 0x60tr one launch per head;
                               tr = 0x04/0x08/0x10 rows per chunk, 0x24/0x28 two chunks in flight).
-                              Bits 16..21, K-pivot paths: 0x10000 diagnostic time stamps of the loop
+                              Bits 16..22, K-pivot paths: 0x10000 diagnostic time stamps of the loop
                               heads, 0x20000 loop heads not confined to one XCD, 0x40000 confined
                               but hand-offs through the memory side, 0x80000 the sweep does not
                               leave the heads' XCD to them, 0x100000 it does so only once this
                               launch's heads have said where they are (no hint from the previous
                               launch), 0x200000 the heads of a step follow their predecessor
                               at once and wait for the previous sweep on a device flag instead of
-                              a cross-stream event (3 % faster; needs concurrent kernels, so not
-                              usable under tools that serialise them, e.g. rocprofv3 --pmc). */
+                              a cross-stream event, 0x400000 the sweep of a step follows its
+                              predecessor at once and asks the heads' completion word as it starts.
+                              Both need the two kernels of a step to run at the same time (tools
+                              that serialise kernels -- rocprofv3 --pmc -- prevent that: the
+                              bounded waits then end the solve with LPR_DEVICE_ERROR) and neither
+                              is faster than the events any more: opt-in only. */
     int32_t block;         /* pivots decided ahead and applied per sweep of the tableau on large
                               tableaux: 0 auto (16), 1 one pivot per sweep, 2..16 that many.  The bits
                               stored are the same for every value (each element goes through the

@@ -953,7 +953,7 @@ int lpr_primal_solve(lpr_tableau* t, const lpr_solve_opts* opts, lpr_solve_resul
     lpr_solve_opts o;
     std::memset(&o, 0, sizeof o);
     if (opts) o = *opts;
-    const int hflags = (o.variant >> 16) & 63;  // loop-head placement / diagnostics (K-pivot paths)
+    const int hflags = (o.variant >> 16) & 255;  // loop-head placement / diagnostics (K-pivot paths)
     o.variant &= 0xffff;                       // path + tile
     lpr_engine* e = t->eng;
     hipStream_t s = e->stream;

@@ -46,6 +46,12 @@ constexpr int kOvMax = 16;      // pivots per block, upper bound
 constexpr int kOvNT = 256;      // threads per workgroup (heads and tiles)
 constexpr int kOvGroups = 64;   // head workgroups, upper bound
 constexpr unsigned kOvSpinMax = 1u << 22;
+// B.sflag also holds kOvDoneCopies copies of the heads' completion count, one per 4 352 bytes (in
+// different memory channels): the ~900 workgroups of a sweep that ask for it poll 32 different
+// lines, not one (all on one word measured as a hot spot that slowed the heads' last gathers)
+constexpr int kOvDoneCopies = 32;
+constexpr int kOvDoneStride = 1088;  // in words
+constexpr size_t kOvFlagWords = (size_t)(kOvDoneCopies + 1) * kOvDoneStride;
 #ifndef LPR_OV_TILE_ROWS
 #define LPR_OV_TILE_ROWS 32  // (tools/sweep_bench.hip overrides it)
 #endif
@@ -89,7 +95,10 @@ struct OvBuffers {      // everything the step kernel touches, passed by value
     unsigned long long* xgran;  // [kOvGroups] {launch epoch, XCC id} of every head workgroup
     unsigned long long* hx;     // {launch epoch, 0x100 | XCC id}: the XCD this launch's heads share
     unsigned* tileq;            // [2] next tile of the sweep (work queue), by launch parity
-    unsigned* sflag;            // sweeps completed in this solve call (stored by the next sweep's start)
+    unsigned* sflag;            // [0] sweeps completed in this solve call (stored by the next sweep's
+                                // start); [1] head launches completed (stored by the workgroup of
+                                // a head launch that finishes last); [2] its arrival counter;
+                                // [3] a sweep gave up waiting for [1]
     unsigned long long* dbg;    // diagnostic time stamps of the lead head workgroup (or null)
     OvCtl* ctl;         // [2]
     unsigned* bar;      // [2]
@@ -99,7 +108,10 @@ struct OvBuffers {      // everything the step kernel touches, passed by value
 
 constexpr int kOvStampsPerPivot = 12;   // diagnostic build of the heads (opts.variant bit 16)
 constexpr int kOvStampPivots = 64;      // pivots kept (a ring over the launches)
-constexpr size_t kOvDbgWords = (size_t)kOvStampPivots * kOvStampsPerPivot + 8;  // + xcc, mode
+// + xcc, mode, 6 spare; then per launch parity 8 words: heads entry / tableau ready / last head done /
+// completion published, sweep (first workgroup) entry / heads' word seen
+constexpr size_t kOvDbgLaunch = (size_t)kOvStampPivots * kOvStampsPerPivot + 8;
+constexpr size_t kOvDbgWords = kOvDbgLaunch + 64;  // a ring over 8 steps
 
 // ------------------------------------------------------------------------------------------
 // Per solve call: Z row, RHS column and entering column of the tableau in memory.
@@ -124,7 +136,8 @@ __global__ __launch_bounds__(1024) void k_ov_prologue(const double* __restrict__
     if (tid < 4) bar[tid] = 0u;
     if (tid < 2) tileq[tid] = 0u;
     if (tid == 0) *hx = 0ull;
-    if (tid == 0) *sflag = 0u;
+    if (tid < 4) sflag[tid] = 0u;
+    if (tid < kOvDoneCopies) sflag[(size_t)(tid + 1) * kOvDoneStride] = 0u;
     __syncthreads();
     Cand c;
     c.v = 0.0;
@@ -791,7 +804,8 @@ __device__ __forceinline__ void ov_publish_min(Cand c, double* lds_v, int* lds_i
 // same step only reads the control block.
 template <int NT, bool STAMP>
 __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, int K, int G, int lp,
-                              bool solo, int spread, int no_l2, int wait_sweeps) {
+                              bool solo, int spread, int no_l2, int wait_sweeps,
+                              int heads_done = -1) {
     if ((int)blockIdx.x % spread != 0) return;
     __shared__ double lds_v[16];
     __shared__ int lds_i[16];
@@ -814,6 +828,7 @@ __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, i
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned long long* stamp = nullptr;
     if (STAMP && lead && tid == 0) stamp = B.dbg;
+    if (STAMP && stamp) B.dbg[kOvDbgLaunch + 8 * ((staged0 / 16) & 7) + 0] = ov_now();
 #define OV_STAMP(q_, k_)                                                                       \
     do {                                                                                       \
         if (STAMP && stamp)                                                                    \
@@ -924,6 +939,7 @@ __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, i
                 __syncthreads();
             }
             if (STAMP && stamp) {
+                B.dbg[kOvDbgLaunch + 8 * ((staged0 / 16) & 7) + 1] = ov_now();
                 B.dbg[(size_t)kOvStampPivots * kOvStampsPerPivot + 0] = my_xcc;
                 B.dbg[(size_t)kOvStampPivots * kOvStampsPerPivot + 1] = l2 ? 1u : 0u;
             }
@@ -1302,6 +1318,7 @@ __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, i
     }
 #undef OV_STAMP
 
+    if (STAMP && stamp) B.dbg[kOvDbgLaunch + 8 * ((staged0 / 16) & 7) + 2] = ov_now();
     if (lead && tid == 0) {  // the next launch's view (fields owned by the heads)
         const bool staged_now = (status == kRunning && pend_in == kRunning);
         if (wait_sweeps > 0 && !staged_now) {
@@ -1338,6 +1355,32 @@ __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, i
             co->applied = ci->applied;
             co->cur = ci->cur;
             co->sweep = ci->sweep;
+        }
+    }
+    if (heads_done >= 0) {
+        // The sweep of the next step does not wait for this launch by an event: it polls
+        // B.sflag[1] as it starts (ov_tiles).  So this launch says itself when everything it
+        // staged (pivot rows, factor columns, the control block) has left this XCD's L2: every
+        // wave drains its stores, the workgroup's lane 0 writes the L2 back (agent-scope release)
+        // and arrives; the workgroup that arrives last publishes the count.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            const unsigned old = __hip_atomic_fetch_add(B.sflag + 2, 1u, __ATOMIC_RELAXED,
+                                                        __HIP_MEMORY_SCOPE_AGENT);
+            s_pick[0] = (old + 1u == (unsigned)G) ? 1 : 0;
+            if (s_pick[0])
+                __hip_atomic_store(B.sflag + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (s_pick[0]) {  // the workgroup that arrived last: the count, and its copies
+            if (tid <= kOvDoneCopies)
+                __hip_atomic_store(tid == 0 ? B.sflag + 1 : B.sflag + (size_t)tid * kOvDoneStride,
+                                   (unsigned)heads_done, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            if (STAMP && tid == 0)
+                B.dbg[kOvDbgLaunch + 8 * ((staged0 / 16) & 7) + 3] = ov_now();
         }
     }
 }
@@ -1592,20 +1635,74 @@ template <int TR, bool DB, bool INPLACE, int TROWS = kOvTileRows>
 __device__ __forceinline__ void ov_tiles(const OvBuffers& B, const double* __restrict__ fcol,
                                          const double* __restrict__ prow, int ld, int R, int Rp,
                                          int G, int lp, int static_tile, int avoid,
-                                         bool write_ctl = true, int sweeps_done = -1) {
+                                         bool write_ctl = true, int sweeps_done = -1,
+                                         int wait_heads = -1, int hint_xcc = -1) {
     static_assert(TROWS % TR == 0 && (!DB || TROWS % (2 * TR) == 0) && TROWS <= 64,
                   "tile rows: a multiple of the chunks in flight, and one bit each in prmask");
     __shared__ int s_tile;
+    const bool first_wg = ((int)blockIdx.x == G);
+    // this launch has started, so every earlier sweep of the stream is complete and its stores
+    // are visible (kernel boundary): tell the heads that wait for exactly that
+    if (first_wg && threadIdx.x == 0 && sweeps_done >= 0)
+        __hip_atomic_store(B.sflag, (unsigned)sweeps_done, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    if (first_wg && threadIdx.x == 0 && !INPLACE && B.dbg)
+        B.dbg[kOvDbgLaunch + 8 * (wait_heads > 0 ? (wait_heads & 7)
+                                                  : (int)((B.ctl[lp].applied / 16 + 1) & 7)) + 4] = ov_now();
+    if (wait_heads > 0) {
+        // No event ordered this launch behind the loop heads that staged its block: it followed
+        // the previous sweep at once (a wait packet costs the command processor ~10 us whether it
+        // has to wait or not) and every workgroup asks the heads' own completion word, B.sflag[1],
+        // before it reads anything they wrote.  Usually the answer is there.  If it is not, the
+        // workgroups that sit on the XCD the heads are expected on (the host's hint, from its last
+        // poll) leave instead of waiting -- a loop-head launch that cannot become resident never
+        // publishes -- and the others poll.  Any workgroup may leave: the tiles are dealt from a
+        // queue.  Only the first one stays whatever happens (it resets the other queue).
+        if (threadIdx.x == 0) {
+            int go = 0;  // 1: proceed, 0: leave, -1: gave up
+            const unsigned* word =
+                B.sflag + (size_t)(1 + ((int)blockIdx.x & (kOvDoneCopies - 1))) * kOvDoneStride;
+            auto ready = [&]() {
+                return __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >=
+                       (unsigned)wait_heads;
+            };
+            if (!first_wg && hint_xcc >= 0 && (int)ov_xcc_id() == hint_xcc) {
+                go = 0;  // (whether the word is there or not: these workgroups would leave anyway)
+            } else if (ready()) {
+                go = 1;
+            } else {
+                go = -1;
+                for (unsigned spins = 0; spins < kOvSpinMax; ++spins) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (ready()) {
+                        go = 1;
+                        break;
+                    }
+                }
+                if (go < 0)
+                    __hip_atomic_store(B.sflag + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            s_tile = go;
+        }
+        __syncthreads();
+        const int go = s_tile;
+        __syncthreads();
+        if (go <= 0) return;
+        if (first_wg && threadIdx.x == 0 && B.dbg) B.dbg[kOvDbgLaunch + 8 * (wait_heads & 7) + 5] = ov_now();
+        // what the heads stored is in memory (they wrote their L2 back before publishing); nothing
+        // of it can be in this XCD's caches from before the wait (they were invalidated when the
+        // launch started and nothing has been read since), the fence makes that explicit.  Not on
+        // the heads' own XCD (only the first workgroup can still be there): it reads through the
+        // very L2 they wrote, and an invalidate of that L2 under the running heads of the NEXT
+        // step cost them 30 us (tools/step_anatomy.py, every other step 210 us instead of 185).
+        if (!(hint_xcc >= 0 && (int)ov_xcc_id() == hint_xcc))
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __builtin_amdgcn_s_dcache_inv();
+    }
     const OvCtl* ci = B.ctl + lp;
     const int K = (ci->status == kRunning) ? ci->kdone : 0;
     const int cur = ci->cur;
-    const bool first_wg = ((int)blockIdx.x == G);
     if (first_wg && threadIdx.x == 0) {  // the next launch's view (fields owned by the sweep)
-        // this launch has started, so every earlier sweep of the stream is complete and its
-        // stores are visible (kernel boundary): tell the heads that wait for exactly that
-        if (sweeps_done >= 0)
-            __hip_atomic_store(B.sflag, (unsigned)sweeps_done, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
         OvCtl* co = B.ctl + (lp ^ 1);
         if (write_ctl) {  // (the heads write these when they run ahead of the event, see there)
             co->applied = ci->applied + K;
@@ -1699,8 +1796,9 @@ __global__ __launch_bounds__(kOvNT) void k_ov_step(const OvBuffers B,
 template <int NT, bool STAMP>
 __global__ __launch_bounds__(NT) void k_ov2_heads(const OvBuffers B, int ld, int R, int C, int Rp,
                                                   int K, int G, int lp, int spread, int no_l2,
-                                                  int wait_sweeps) {
-    ov_heads_rich<NT, STAMP>(B, ld, R, C, Rp, K, G, lp, false, spread, no_l2, wait_sweeps);
+                                                  int wait_sweeps, int heads_done) {
+    ov_heads_rich<NT, STAMP>(B, ld, R, C, Rp, K, G, lp, false, spread, no_l2, wait_sweeps,
+                             heads_done);
 }
 
 
@@ -1710,9 +1808,10 @@ __global__ __launch_bounds__(kOvNT) void k_ov2_sweep(const OvBuffers B,
                                                      const double* __restrict__ fcol_ro,
                                                      const double* __restrict__ prow_ro, int ld,
                                                      int R, int Rp, int lp, int avoid,
-                                                     int write_ctl, int sweeps_done) {
+                                                     int write_ctl, int sweeps_done,
+                                                     int wait_heads, int hint_xcc) {
     ov_tiles<TR, DB, false>(B, fcol_ro, prow_ro, ld, R, Rp, 0, lp, -1, avoid, write_ctl != 0,
-                            sweeps_done);
+                            sweeps_done, wait_heads, hint_xcc);
 }
 
 // The same two halves as separate launches: all K loop heads of a block in ONE persistent launch
@@ -1752,6 +1851,9 @@ struct lpr_overlap_ctx {
     int ev_idx = 0;
     int steps = 0;                  // launch pairs queued by the current solve call
     hipEvent_t last_sweep = nullptr;  // the event that marks the latest sweep of the call as done
+    unsigned* h_flags = nullptr;    // pinned copy of b.sflag[0..3]
+    int head_xcc_hint = -1;         // the XCD the loop heads shared at the last poll (-1: unknown)
+    bool batch_first = true;        // the next step is the first after the streams were joined
 };
 
 namespace lpr {
@@ -1792,6 +1894,7 @@ void ov_release(lpr_tableau* t) {
     hipFree(c->b.bar);
     if (c->h_ctl) hipHostFree(c->h_ctl);
     if (c->h_z) hipHostFree(c->h_z);
+    if (c->h_flags) hipHostFree(c->h_flags);
     delete c;
     t->ov = nullptr;
 }
@@ -1822,11 +1925,12 @@ int ov_ensure(lpr_tableau* t, bool second_buffer) {
     chk(hipMalloc(&c->b.dbg, kOvDbgWords * sizeof(unsigned long long)));
     chk(hipMalloc(&c->b.hx, 2 * sizeof(unsigned long long)));
     chk(hipMalloc(&c->b.tileq, 4 * sizeof(unsigned)));
-    chk(hipMalloc(&c->b.sflag, 4 * sizeof(unsigned)));
+    chk(hipMalloc(&c->b.sflag, kOvFlagWords * sizeof(unsigned)));
     chk(hipMalloc(&c->b.ctl, 2 * sizeof(OvCtl)));
     chk(hipMalloc(&c->b.bar, 4 * sizeof(unsigned)));
     chk(hipHostMalloc(&c->h_ctl, 2 * sizeof(OvCtl)));
     chk(hipHostMalloc(&c->h_z, 2 * sizeof(double)));
+    chk(hipHostMalloc(&c->h_flags, 4 * sizeof(unsigned)));
     t->ov = c;
     if (err != hipSuccess) {
         set_error("overlapped-pivot scratch allocation failed: %s", hipGetErrorString(err));
@@ -1841,7 +1945,9 @@ int ov_ensure(lpr_tableau* t, bool second_buffer) {
     LPR_HIP(hipMemsetAsync(c->b.bvec, 0, (size_t)2 * c->Rp * D, s));
     LPR_HIP(hipMemsetAsync(c->b.zparts, 0, (size_t)2 * kOvGroups * sizeof(ZPart), s));
     LPR_HIP(hipMemsetAsync(c->b.dbg, 0, kOvDbgWords * sizeof(unsigned long long), s));
+    LPR_HIP(hipMemsetAsync(c->b.sflag, 0, kOvFlagWords * sizeof(unsigned), s));
     std::memset(c->h_ctl, 0, 2 * sizeof(OvCtl));
+    std::memset(c->h_flags, 0, 4 * sizeof(unsigned));
     return LPR_OK_OPTIMAL;
 }
 
@@ -1991,6 +2097,7 @@ int ov2_begin(lpr_tableau* t) {
     // everything queued on the engine stream so far (prologue, control block) precedes step 0
     c->ev_idx = 0;
     c->steps = 0;
+    c->batch_first = true;
     LPR_HIP(hipEventRecord(c->ev_s[1], t->eng->stream));
     LPR_HIP(hipEventRecord(c->ev_h[1], c->hstream));
     c->last_sweep = c->ev_s[1];
@@ -2011,22 +2118,30 @@ int ov2_launch_step(lpr_tableau* t, int K, int tr, int lp, int flags, hipEvent_t
     // so it is opt-in.
     const bool by_event = (flags & 32) == 0;
     const int wait_sweeps = by_event ? -1 : c->steps;
+    // flags 64: the SWEEP does not wait for the heads of the step before by an event either: it
+    // follows its predecessor on the engine stream at once and asks the heads' completion word as
+    // it starts (ov_tiles).  Not for the first step after the streams were joined, nor for the
+    // first two steps of a call (the heads it would wait for may not be resident yet: they
+    // could find the chip full of polling sweep workgroups), nor while the heads' XCD is unknown.
+    const bool sweep_dev = (flags & 64) != 0 && !c->batch_first && c->steps >= 2 &&
+                           c->head_xcc_hint >= 0;
+    const int heads_done = (flags & 64) ? c->steps + 1 : -1;
     // The events that order the two streams (and the ones that time a sampled step) are the
     // completion signals of the kernels themselves (hipExtLaunchKernelGGL's stop event): a separate
     // hipEventRecord is a packet of its own on the stream, ~3 us each on the critical cycle.
     if (by_event) LPR_HIP(hipStreamWaitEvent(H, c->last_sweep, 0));
-    LPR_HIP(hipStreamWaitEvent(S, c->ev_h[prev], 0));
+    if (!sweep_dev) LPR_HIP(hipStreamWaitEvent(S, c->ev_h[prev], 0));
     const int G = ov_groups(t);
     const int spread = ov_spread(G, flags);
     const int no_l2 = (flags & 6) ? 1 : 0;
     if (flags & 1)
         hipExtLaunchKernelGGL((k_ov2_heads<kOvNT, true>), dim3(G * spread), dim3(kOvNT), 0, H,
                               nullptr, c->ev_h[cur], 0, c->b, t->ld, t->rows, t->cols, c->Rp, K, G,
-                              lp, spread, no_l2, wait_sweeps);
+                              lp, spread, no_l2, wait_sweeps, heads_done);
     else
         hipExtLaunchKernelGGL((k_ov2_heads<kOvNT, false>), dim3(G * spread), dim3(kOvNT), 0, H,
                               nullptr, c->ev_h[cur], 0, c->b, t->ld, t->rows, t->cols, c->Rp, K, G,
-                              lp, spread, no_l2, wait_sweeps);
+                              lp, spread, no_l2, wait_sweeps, heads_done);
     const int nct = (t->ld / 2 + kOvNT - 1) / kOvNT;
     const int nrt = (t->rows + kOvTileRows - 1) / kOvTileRows;
     const dim3 grid(ov_sweep_grid(t, nct * nrt)), blk(kOvNT);
@@ -2039,7 +2154,7 @@ int ov2_launch_step(lpr_tableau* t, int K, int tr, int lp, int flags, hipEvent_t
 #define LPR_OV2_SWEEP(TR, DB)                                                                     \
     hipExtLaunchKernelGGL((k_ov2_sweep<TR, DB>), grid, blk, 0, S, ev_start, sweep_done, 0, c->b,   \
                           c->b.fcol, c->b.prow, t->ld, t->rows, c->Rp, lp, avoid, by_event ? 1 : 0, \
-                          by_event ? -1 : c->steps)
+                          by_event ? -1 : c->steps, sweep_dev ? c->steps : -1, c->head_xcc_hint)
     switch (ov_tile_code(tr)) {
         case 0x04: LPR_OV2_SWEEP(4, false); break;
         case 0x10: LPR_OV2_SWEEP(16, false); break;
@@ -2051,6 +2166,7 @@ int ov2_launch_step(lpr_tableau* t, int K, int tr, int lp, int flags, hipEvent_t
     c->last_sweep = sweep_done;
     c->steps += 1;
     c->ev_idx = prev;
+    c->batch_first = false;
     return LPR_OK_OPTIMAL;
 }
 
@@ -2058,6 +2174,7 @@ int ov2_launch_step(lpr_tableau* t, int K, int tr, int lp, int flags, hipEvent_t
 int ov2_join(lpr_tableau* t) {
     lpr_overlap_ctx* c = static_cast<lpr_overlap_ctx*>(t->ov);
     LPR_HIP(hipStreamWaitEvent(t->eng->stream, c->ev_h[c->ev_idx ^ 1], 0));
+    c->batch_first = true;
     return LPR_OK_OPTIMAL;
 }
 
@@ -2070,13 +2187,15 @@ int ov_poll(lpr_tableau* t, int parity, OvPoll* out) {
     LPR_HIP(hipMemcpyAsync(&c->h_z[0], c->b.bvec, sizeof(double), hipMemcpyDeviceToHost, s));
     LPR_HIP(hipMemcpyAsync(&c->h_z[1], c->b.bvec + c->Rp, sizeof(double), hipMemcpyDeviceToHost,
                            s));
+    LPR_HIP(hipMemcpyAsync(c->h_flags, c->b.sflag, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
     LPR_HIP(hipStreamSynchronize(s));
     const OvCtl& h = c->h_ctl[parity];
+    c->head_xcc_hint = h.head_xcc;
     out->status = h.status;
     out->pending = h.pending;
     out->kdone = h.kdone;
     out->cur = h.cur;
-    out->error = h.error;
+    out->error = h.error | (c->h_flags[3] ? 1 : 0);  // (a sweep gave up waiting for its heads)
     out->applied = h.applied;
     out->z[0] = c->h_z[0];
     out->z[1] = c->h_z[1];

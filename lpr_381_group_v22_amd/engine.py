@@ -232,6 +232,16 @@ class Tableau:
                                             buf.size, C.byref(cnt)), "lpr_debug_head_stamps")
         return buf[:64 * 12].reshape(64, 12), int(buf[64 * 12]), int(buf[64 * 12 + 1])
 
+    def launch_stamps(self):
+        """Diagnostic (variant bit 16, two-stream path): a ring over 8 steps, 10 ns ticks of
+        [heads entry, tableau ready, last head done, completion published, sweep entry, sweep saw
+        the heads' word, -, -]."""
+        buf = np.zeros(64 * 12 + 8 + 64, dtype=np.uint64)
+        cnt = C.c_int64()
+        N.check(N.lib.lpr_debug_head_stamps(self._h, buf.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                            buf.size, C.byref(cnt)), "lpr_debug_head_stamps")
+        return buf[64 * 12 + 8:].reshape(8, 8)
+
 
 class RevisedState:
     """Device-resident state of the revised primal simplex (lpr_revised_*)."""

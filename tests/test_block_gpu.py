@@ -22,10 +22,14 @@ SEQ, OV, INPLACE, OV2 = 0x4008, 0x5008, 0x6008, 0x3008
 # memory-side hand-offs, STAMPS = the diagnostic build.  Same bits every way.
 STAMPS, SPREAD, MEMSIDE = 0x10000, 0x20000, 0x40000
 NOAVOID, NOHINT, DEVHAND = 0x80000, 0x100000, 0x200000  # sweep / hand-over variants (ABI header)
+# SWEEPDEV = the sweep of a step asks the heads' completion word as it starts instead of waiting
+# for an event on its stream (opt-in, like DEVHAND for the other direction)
+SWEEPDEV = 0x400000
 NAMES = {SEQ: "seq", OV: "ov", INPLACE: "inplace", OV2: "ov2",
          SEQ | SPREAD: "seq-spread", OV2 | SPREAD: "ov2-spread", OV2 | MEMSIDE: "ov2-memside",
          SEQ | STAMPS: "seq-stamps", OV2 | STAMPS: "ov2-stamps",
          OV2 | DEVHAND: "ov2-devhand", OV2 | NOAVOID: "ov2-noavoid", OV2 | NOHINT: "ov2-nohint",
+         OV2 | DEVHAND | SWEEPDEV: "ov2-dev2", OV2 | SWEEPDEV: "ov2-sweepdev",
          0x3024: "ov2-2x4", 0x3028: "ov2-2x8", 0x3004: "ov2-4", 0x3010: "ov2-16",
          0x4024: "seq-2x4", 0x4028: "seq-2x8", 0x4010: "seq-16"}
 # (variant, block)
@@ -34,6 +38,7 @@ BLOCKS = [(SEQ, 2), (SEQ, 5), (SEQ, 8), (SEQ, 16), (OV, 2), (OV, 3), (OV, 8), (O
           (INPLACE, 2), (INPLACE, 4), (INPLACE, 8),
           (SEQ | SPREAD, 16), (OV2 | SPREAD, 16), (OV2 | MEMSIDE, 9), (SEQ | STAMPS, 16),
           (OV2 | STAMPS, 13), (OV2 | DEVHAND, 16), (OV2 | DEVHAND, 3), (OV2 | NOAVOID, 16), (OV2 | NOHINT, 6),
+          (OV2 | DEVHAND | SWEEPDEV, 16), (OV2 | SWEEPDEV, 5),
           (0x3024, 16), (0x3028, 16), (0x3004, 16), (0x3010, 16),
           (0x4024, 16), (0x4028, 11), (0x4010, 16)]
 IDS = [NAMES[v] + str(b) for v, b in BLOCKS]
@@ -323,9 +328,10 @@ def north_star_64(oracle):
 
 
 @pytest.mark.parametrize("variant", [0, SPREAD, MEMSIDE, DEVHAND, NOAVOID, 0x4008, 0x5008, 0x3024,
-                                     0x3028, 0x3004],
+                                     0x3028, 0x3004, DEVHAND | SWEEPDEV],
                          ids=["default", "default-spread", "default-memside", "default-devhand",
-                              "default-noavoid", "seq", "ov", "ov2-2x4", "ov2-2x8", "ov2-4"])
+                              "default-noavoid", "seq", "ov", "ov2-2x4", "ov2-2x8", "ov2-4",
+                              "default-dev2"])
 def test_north_star_size_64_pivots_vs_oracle(engine, north_star_64, variant):
     """BASELINE's headline size (m=4096, n=8192: 4097 x 12289, 25 loop-head workgroups): four full
     blocks of 16 -- from the second on, the next block's heads run beside the sweep -- against the
@@ -336,6 +342,25 @@ def test_north_star_size_64_pivots_vs_oracle(engine, north_star_64, variant):
     tab = Tableau.synthetic(engine, 4096, 8192, 0)
     res = tab.solve(max_pivots=64, variant=variant)
     assert res.status == st and res.pivots == 64 and res.block == 16
+    assert tab.pivot_log().tolist() == log.tolist()
+    assert tab.basis().tolist() == basis.tolist()
+    assert hashlib.sha256(tab.read().tobytes()).hexdigest() == sha
+    tab.destroy()
+
+
+@pytest.mark.parametrize("variant", [DEVHAND | SWEEPDEV, SWEEPDEV], ids=["dev2", "sweepdev"])
+def test_north_star_size_sweep_asks_the_heads_word_vs_oracle(engine, north_star_64, variant):
+    """The sweep-side device hand-over only starts once a poll has told the host which XCD the
+    loop heads share and from the third step of a call on: 16 pivots first (one poll), then 48 in
+    a second call, whose last two sweeps follow their predecessors without an event and ask the
+    heads' completion word (B.sflag[1]) themselves.  Same oracle data as the test above."""
+    from lpr_381_group_v22_amd import Tableau
+    st, log, basis, sha = north_star_64
+    tab = Tableau.synthetic(engine, 4096, 8192, 0)
+    r1 = tab.solve(max_pivots=16, variant=variant)
+    assert r1.pivots == 16 and r1.block == 16
+    res = tab.solve(max_pivots=48, variant=variant)
+    assert res.status == st and res.pivots == 48 and res.total_pivots == 64
     assert tab.pivot_log().tolist() == log.tolist()
     assert tab.basis().tolist() == basis.tolist()
     assert hashlib.sha256(tab.read().tobytes()).hexdigest() == sha

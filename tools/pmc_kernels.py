@@ -30,9 +30,13 @@ def main():
             return statistics.median(big) * 1024.0, len(big)
         fb, nf = med(f.get(name, []))
         wb, nw = med(w.get(name, []))
+        tot = 2 * 1024.0 * sum(f.get(name, [])) + 1024.0 * sum(w.get(name, []))
         out["kernels"][name] = {"fetch_bytes_raw": fb, "fetch_bytes_corrected_x2": 2 * fb,
                                 "write_bytes": wb, "hbm_side_bytes": 2 * fb + wb,
-                                "working_dispatches": min(nf, nw) if nf and nw else max(nf, nw)}
+                                "working_dispatches": min(nf, nw) if nf and nw else max(nf, nw),
+                                # all dispatches of the run (levels of a B&B tree differ in width)
+                                "dispatches": max(len(f.get(name, [])), len(w.get(name, []))),
+                                "hbm_side_bytes_all_dispatches": tot}
     json.dump(out, sys.stdout, indent=1)
 
 
