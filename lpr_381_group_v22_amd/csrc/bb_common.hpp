@@ -76,6 +76,9 @@ struct lpr_bb {
     int32_t* blist = nullptr;         // slot_cap x ld   sorted basic columns
     int32_t* bcount = nullptr;        // slot_cap
     int32_t* rowlist = nullptr;       // slot_cap x rows_cap: rows the pending pivot changes
+    uint8_t* touched = nullptr;       // slot_cap x align_up(rows_cap, 16): 1 = some pivot of this
+                                      // child's DoDualSimplex (or AddConstraint's elimination) has
+                                      // written the row since k_bb_child_init rounded it
     int32_t* trace = nullptr;         // slot_cap x trace_cap x 3 (phase, row, col)
     int trace_cap = 0;
     double* info = nullptr;           // slot_cap x (nvars + 1): z, decision values

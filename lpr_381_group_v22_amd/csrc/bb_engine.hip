@@ -74,7 +74,9 @@ static void bb_release_device(lpr_bb* b) {
     hipFree(b->d_slots); hipFree(b->rowbuf); hipFree(b->colbuf); hipFree(b->bflag);
     hipFree(b->bkey); hipFree(b->blist); hipFree(b->bcount); hipFree(b->trace); hipFree(b->info);
     hipFree(b->rowlist);
+    hipFree(b->touched);
     b->rowlist = nullptr;
+    b->touched = nullptr;
     hipFree(b->d_running);
     if (b->h_slots) hipHostFree(b->h_slots);
     if (b->h_info) hipHostFree(b->h_info);
@@ -146,7 +148,9 @@ static int bb_ensure_slots(lpr_bb* b, int need) {
     hipFree(b->d_slots); hipFree(b->rowbuf); hipFree(b->colbuf); hipFree(b->bflag);
     hipFree(b->bkey); hipFree(b->blist); hipFree(b->bcount); hipFree(b->trace); hipFree(b->info);
     hipFree(b->rowlist);
+    hipFree(b->touched);
     b->rowlist = nullptr;
+    b->touched = nullptr;
     if (b->h_slots) hipHostFree(b->h_slots);
     if (b->h_info) hipHostFree(b->h_info);
     b->d_slots = b->h_slots = nullptr;
@@ -164,6 +168,7 @@ static int bb_ensure_slots(lpr_bb* b, int need) {
     LPR_HIP(hipMalloc(&b->blist, S * b->ld * sizeof(int32_t)));
     LPR_HIP(hipMalloc(&b->bcount, S * sizeof(int32_t)));
     LPR_HIP(hipMalloc(&b->rowlist, S * b->rows_cap * sizeof(int32_t)));
+    LPR_HIP(hipMalloc(&b->touched, S * align_up(b->rows_cap, 16)));
     LPR_HIP(hipMalloc(&b->trace, S * b->trace_cap * 3 * sizeof(int32_t)));
     LPR_HIP(hipMalloc(&b->info, S * (b->nvars + 1) * sizeof(double)));
     LPR_HIP(hipHostMalloc(&b->h_info, S * (b->nvars + 1) * sizeof(double)));

@@ -130,14 +130,21 @@ __device__ __forceinline__ int block_min_int(int v, int* lds) {
 // :747).
 constexpr int kBBRowsPerThread = 8;  // rows a thread of the element-wise passes walks
 
-__global__ __launch_bounds__(256) void k_bb_child_init(const BBSlot* __restrict__ slots, int ld) {
+__global__ __launch_bounds__(256) void k_bb_child_init(const BBSlot* __restrict__ slots, int ld,
+                                                       uint8_t* __restrict__ touched_all,
+                                                       int rows_cap16) {
     const BBSlot& s = slots[blockIdx.z];
     const int Rc = s.rows, Cc = s.cols;
     const int R = Rc - 1, C = Cc - 1;  // parent shape
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i0 = blockIdx.y * kBBRowsPerThread;
+    // every row starts as a rounded copy of the parent's: untouched -- except the appended row,
+    // which k_bb_eliminate rewrites (:756-796)
+    if (blockIdx.x == 0 && threadIdx.x < kBBRowsPerThread && i0 + (int)threadIdx.x < rows_cap16)
+        touched_all[(size_t)blockIdx.z * rows_cap16 + i0 + threadIdx.x] =
+            (i0 + (int)threadIdx.x == Rc - 1) ? 1 : 0;
     if (j >= ld) return;
     const double* __restrict__ P = s.parent;
-    const int i0 = blockIdx.y * kBBRowsPerThread;
 #pragma unroll
     for (int d = 0; d < kBBRowsPerThread; ++d) {
         const int i = i0 + d;
@@ -320,7 +327,9 @@ __global__ __launch_bounds__(1024) void k_bb_select(BBSlot* slots, double* __res
                                                     int rows_cap, int32_t* __restrict__ trace_all,
                                                     int trace_cap, int32_t* running,
                                                     int step_no,
-                                                    int32_t* __restrict__ rowlist_all) {
+                                                    int32_t* __restrict__ rowlist_all,
+                                                    uint8_t* __restrict__ touched_all,
+                                                    int rows_cap16) {
     __shared__ double lds_v[16];
     __shared__ int lds_i[16];
     __shared__ int s_cnt;
@@ -549,7 +558,10 @@ __global__ __launch_bounds__(1024) void k_bb_select(BBSlot* slots, double* __res
         for (int i = tid; i < R; i += nt) {
             const double f = cur[(size_t)i * ld + pc];
             colbuf[i] = f;
-            if (nonfinite || f != 0.0 || i == pr) list[atomicAdd(&s_cnt, 1)] = i;
+            if (nonfinite || f != 0.0 || i == pr) {
+                list[atomicAdd(&s_cnt, 1)] = i;
+                touched_all[(size_t)blockIdx.x * rows_cap16 + i] = 1;  // (k_bb_finish)
+            }
             double nr;
             if (i == pr) {
                 nr = prhs;
@@ -670,10 +682,18 @@ __global__ __launch_bounds__(256) void k_bb_update(const BBSlot* __restrict__ sl
 // Valid while no rounded entry is >= 1e11 or non-finite (slot.big, as in k_bb_round): below that
 // RoundNumber is idempotent, so the second rounding of the pop (:1047) and the roundings the
 // consumers apply on top change nothing; a big node goes through the separate kernels.
+// A row no pivot has written since k_bb_child_init stored it (touched == 0: ~2/3 of the rows of a
+// child on the bench instance) holds values that have been through RoundNumber already, and below
+// 2.2e11 RoundNumber gives such a value back unchanged (x = n / 1e4 rounded: x * 1e4 is within
+// n * 2^-52 of the integer n, which the round-to-even step restores exactly): for those rows the
+// three roundings per entry -- two divisions each, and this kernel is bound by them, not by bytes --
+// are skipped and the entry itself is used.  (>= 1e11 sets slot.big as before.)
 __global__ __launch_bounds__(64) void k_bb_finish(BBSlot* __restrict__ slots, int ld, int rows_cap,
-                                                 int nvars) {
+                                                 int nvars, const uint8_t* __restrict__ touched_all,
+                                                 int rows_cap16) {
     BBSlot& s = slots[blockIdx.y];
     if (s.state != kBBSolved) return;
+    const uint8_t* __restrict__ touched = touched_all + (size_t)blockIdx.y * rows_cap16;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     const int R = s.rows, C = s.cols;
     if (k >= C) return;
@@ -690,17 +710,25 @@ __global__ __launch_bounds__(64) void k_bb_finish(BBSlot* __restrict__ slots, in
 #pragma unroll
         for (int d = 0; d < U; ++d) {
             const int i = i0 + d;
-            if (i < R) {
+            if (i < R && !touched[i]) {  // (the same for every lane: a scalar branch)
+                const double v = x[d];
+                big = big || !(fabs(v) < 1e11);
+                if (i == 0) v0 = v;
+                sum = sum + v;
+                if (key == R && v == 1.0) key = i;
+                if (frow < 0 && fabs(v - 1.0) <= kBBEps) frow = i;
+            } else if (i < R) {
                 const double v = dn_round4(x[d]);          // :1124 / :1187
                 big = big || !(fabs(v) < 1e11);
                 // (most entries are zeros or come from rows no pivot touched since child_init
                 // rounded them: only a value whose bits change is written back)
                 if (__double_as_longlong(v) != __double_as_longlong(x[d])) T[(size_t)i * ld + k] = v;
                 if (i == 0) v0 = v;
-                const double v2 = dn_round4_twice(v);      // working = Round(base) :702, Identify :655
-                sum = sum + v2;
-                if (key == R && v2 == 1.0) key = i;
-                if (frow < 0 && fabs(dn_round4(v) - 1.0) <= kBBEps) frow = i;  // :812-821
+                // working = Round(base) :702, Identify :655, :812-821 round v again: below 1e11
+                // that gives v back (above, slot.big is set and none of this is used)
+                sum = sum + v;
+                if (key == R && v == 1.0) key = i;
+                if (frow < 0 && fabs(v - 1.0) <= kBBEps) frow = i;
             }
         }
     }
@@ -793,7 +821,8 @@ void bb_launch_node_info(lpr_bb* b, int count) {
 
 void bb_launch_finish(lpr_bb* b, int nslots, int cols_max) {
     hipLaunchKernelGGL(k_bb_finish, dim3((cols_max + 63) / 64, nslots), dim3(64), 0, b->eng->stream,
-                       b->d_slots, b->ld, b->rows_cap, b->nvars);
+                       b->d_slots, b->ld, b->rows_cap, b->nvars, b->touched,
+                       align_up(b->rows_cap, 16));
 }
 
 void bb_launch_gather_info(lpr_bb* b, int count) {
@@ -806,7 +835,8 @@ void bb_launch_add_constraint(lpr_bb* b, int nslots, int nparents, int rows_max,
     hipStream_t st = b->eng->stream;
     const dim3 egrid((b->ld + 255) / 256, (rows_max + kBBRowsPerThread - 1) / kBBRowsPerThread,
                      nslots);
-    hipLaunchKernelGGL(k_bb_child_init, egrid, dim3(256), 0, st, b->d_slots, b->ld);
+    hipLaunchKernelGGL(k_bb_child_init, egrid, dim3(256), 0, st, b->d_slots, b->ld, b->touched,
+                       align_up(b->rows_cap, 16));
     if (!side)  // (otherwise every parent carries its scan in its own buffer: k_bb_finish)
         hipLaunchKernelGGL(k_bb_basic_scan, dim3((cols_max + 63) / 64, nparents), dim3(64), 0, st,
                            b->d_slots, b->ld, b->bflag, b->bkey);
@@ -831,7 +861,7 @@ void bb_launch_pivot_step(lpr_bb* b, int nslots, int rows_max, int cols_max, int
     const int threads = (rows_max > 256 || cols_max > 256) ? 1024 : 256;
     hipLaunchKernelGGL(k_bb_select, dim3(nslots), dim3(threads), 0, st, b->d_slots, b->rowbuf,
                        b->colbuf, b->ld, b->rows_cap, b->trace, b->trace_cap, b->d_running, step_no,
-                       b->rowlist);
+                       b->rowlist, b->touched, align_up(b->rows_cap, 16));
     constexpr int TR = 8;
     hipLaunchKernelGGL((k_bb_update<TR>), dim3(1, (rows_max + TR - 1) / TR, nslots), dim3(256), 0, st,
                        b->d_slots, b->rowbuf, b->colbuf, b->rowlist, b->ld, b->rows_cap);
@@ -841,7 +871,7 @@ void bb_launch_select_only(lpr_bb* b, int nslots, int rows_max, int cols_max) {
     const int threads = (rows_max > 256 || cols_max > 256) ? 1024 : 256;
     hipLaunchKernelGGL(k_bb_select, dim3(nslots), dim3(threads), 0, b->eng->stream, b->d_slots,
                        b->rowbuf, b->colbuf, b->ld, b->rows_cap, b->trace, b->trace_cap,
-                       b->d_running, 0, b->rowlist);
+                       b->d_running, 0, b->rowlist, b->touched, align_up(b->rows_cap, 16));
 }
 
 }  // namespace lpr
