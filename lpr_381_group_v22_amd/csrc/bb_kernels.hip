@@ -47,7 +47,7 @@ __device__ __forceinline__ double dn_round4(double x) {
     if (fabs(x) < 1e16) {
         x = x * 10000.0;
         x = dn_round_int(x);
-        x = x / 10000.0;
+        x = ieee_div(x, 10000.0);
     }
     return x;
 }
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(1024) void k_bb_select(BBSlot* slots, double* __res
                 m.i = -1;
                 for (int j = tid; j < C - 1; j += nt) {
                     const double a = prow[j];
-                    const double th = (a < 0) ? fabs(cur[j] / a) : INFINITY;  // :126-143
+                    const double th = (a < 0) ? fabs(ieee_div(cur[j], a)) : INFINITY;  // :126-143
                     if (!(th == 0 || th == INFINITY)) non0inf = 1;
                     if (th > 0 && (m.i < 0 || th < m.v)) {
                         m.v = th;
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(1024) void k_bb_select(BBSlot* slots, double* __res
                     int first = INT_MAX;
                     for (int j = tid; j < C - 1; j += nt) {
                         const double a = prow[j];
-                        const double th = (a < 0) ? fabs(cur[j] / a) : INFINITY;
+                        const double th = (a < 0) ? fabs(ieee_div(cur[j], a)) : INFINITY;
                         if (th == 0) {
                             first = j;
                             break;
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(1024) void k_bb_select(BBSlot* slots, double* __res
                 m.i = -1;
                 for (int i = 1 + tid; i < R; i += nt) {
                     const double a = cur[(size_t)i * ld + pc];
-                    const double th = (a != 0) ? cur[(size_t)i * ld + rhs] / a : INFINITY;
+                    const double th = (a != 0) ? ieee_div(cur[(size_t)i * ld + rhs], a) : INFINITY;
                     if (!(th < 0)) notneg = 1;
                     if (th == 0) has0 = 1;
                     if (th > 0 && th != INFINITY) {
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(1024) void k_bb_select(BBSlot* slots, double* __res
                         int first = INT_MAX;
                         for (int i = 1 + tid; i < R; i += nt) {
                             const double a = cur[(size_t)i * ld + pc];
-                            const double th = (a != 0) ? cur[(size_t)i * ld + rhs] / a : INFINITY;
+                            const double th = (a != 0) ? ieee_div(cur[(size_t)i * ld + rhs], a) : INFINITY;
                             if (th == 0) {
                                 first = i;
                                 break;
@@ -534,13 +534,13 @@ __global__ __launch_bounds__(1024) void k_bb_select(BBSlot* slots, double* __res
         const double* __restrict__ prow = cur + (size_t)pr * ld;
         int nonfinite = 0;
         for (int j = tid; j < ld; j += nt) {
-            double v = (j < C) ? prow[j] / p : 0.0;
+            double v = (j < C) ? ieee_div(prow[j], p) : 0.0;
             if (v == 0.0) v = 0.0;  // `== -0.0` is true for both zeros
             rowbuf[j] = v;
             if (!(fabs(v) < INFINITY)) nonfinite = 1;
         }
         nonfinite = __syncthreads_or(nonfinite);
-        double prhs = prow[rhs] / p;
+        double prhs = ieee_div(prow[rhs], p);
         if (prhs == 0.0) prhs = 0.0;
         if (tid == 0) s_cnt = 0;
         __syncthreads();

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(kBlkHeadNT) void k_blk_head(
             if (i < R) {
                 if (i == 0) lds_p[1] = a[u];
                 if (i >= 1 && a[u] > 1e-9) {
-                    const double ratio = b[u] / a[u];
+                    const double ratio = ieee_div(b[u], a[u]);
                     if (ratio >= 0 && ratio < c.v) {
                         c.v = ratio;
                         c.i = i;
@@ -306,8 +306,8 @@ __global__ __launch_bounds__(kBlkHeadNT) void k_blk_head(
         }
         const int j = 2 * c2;
         double2 pq;
-        pq.x = (j < C) ? w.x / p : 0.0;  // :199 true division
-        pq.y = (j + 1 < C) ? w.y / p : 0.0;
+        pq.x = (j < C) ? ieee_div(w.x, p) : 0.0;  // :199 true division
+        pq.y = (j + 1 < C) ? ieee_div(w.y, p) : 0.0;
         prow2[(size_t)(q - 1) * ld2 + c2] = pq;
         const double mxp = f0 * pq.x;  // :208 product rounded, then the difference
         const double myp = f0 * pq.y;
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(kBlkHeadNT) void k_blk_head(
             }
         }
     }
-    const double prhs = wr / p;
+    const double prhs = ieee_div(wr, p);
     for (int i = g * nt + tid; i < R; i += G * nt) {
         const double a = col[i];
         if (q == 1) fcol[i] = a;

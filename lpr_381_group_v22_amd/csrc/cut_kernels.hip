@@ -53,7 +53,7 @@ __device__ __forceinline__ double dual_ratio(const double* __restrict__ T, int l
     if (!(a < -kCutEps)) return NAN;
     const double num = T[j];
     if (!(fabs(num) > kCutEps)) return NAN;
-    return fabs(num / a);
+    return fabs(ieee_div(num, a));
 }
 
 // Replays `for j ascending: if (ratio < best - EPS || (|ratio - best| <= EPS && (pc == -1 ||
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(1024) void k_cut_select(double* __restrict__ T, int
                 if (i <= pr) continue;
                 const double a = T[(size_t)i * ld + pc];
                 if (!(a > kCutEps)) continue;
-                const double ratio = T[(size_t)i * ld + rhs] / a;
+                const double ratio = ieee_div(T[(size_t)i * ld + rhs], a);
                 const bool second = (fabs(ratio - best) <= kCutEps && pr == -1) ? true : (i < pr);
                 if ((ratio > kCutEps && ratio < best - kCutEps) || second) {
                     first = i;
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(1024) void k_cut_select(double* __restrict__ T, int
             first = cut_block_min_int(first, lds);
             if (first == INT_MAX) break;
             pr = first;
-            best = T[(size_t)pr * ld + rhs] / T[(size_t)pr * ld + pc];
+            best = ieee_div(T[(size_t)pr * ld + rhs], T[(size_t)pr * ld + pc]);
         }
         if (pr < 0) {
             if (tid == 0) st->status = LPR_UNBOUNDED;  // return false :63-68
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(1024) void k_cut_select(double* __restrict__ T, int
         if (tid == 0) st->status = LPR_PIVOT_TOO_SMALL;  // InvalidOperationException :155 / :148
         return;
     }
-    for (int j = tid; j < ld; j += nt) rowbuf[j] = (j < C) ? T[(size_t)pr * ld + j] / piv : 0.0;
+    for (int j = tid; j < ld; j += nt) rowbuf[j] = (j < C) ? ieee_div(T[(size_t)pr * ld + j], piv) : 0.0;
     for (int i = tid; i < R; i += nt) colbuf[i] = T[(size_t)i * ld + pc];
     if (tid == 0) {
         st->pr = pr;
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(1024) void k_cut_add(double* __restrict__ T, int ld
         if (tid == 0) st->scratch[1] = -2;
         return;
     }
-    for (int j = tid; j < ld; j += nt) rowbuf[j] = (j < C) ? T[(size_t)R * ld + j] / piv : 0.0;
+    for (int j = tid; j < ld; j += nt) rowbuf[j] = (j < C) ? ieee_div(T[(size_t)R * ld + j], piv) : 0.0;
     for (int i = tid; i < R + 1; i += nt) colbuf[i] = T[(size_t)i * ld + pc];
     if (tid == 0) {
         st->pr = R;

@@ -41,6 +41,67 @@ const char* get_error();
 
 inline int align_up(int x, int a) { return (x + a - 1) / a * a; }
 
+// a / b, correctly rounded.  The device's own fp64 division (v_div_scale / v_rcp / Newton steps /
+// v_div_fmas / v_div_fixup) ends in ONE fused multiply-add of the residual with an APPROXIMATE
+// reciprocal; when a / b lies within ~1e-16 ulp of the midpoint between two doubles that step can
+// round the other way than IEEE 754 division (what the C#'s `/` is on x64).  Found by
+// tools/fuzz_side_gpu.py: -0x1.6666666666663p+0 / -0x1.ffffffffffffbp+1 is 0.35000000000000003,
+// the device said 0.35 -- a 1-ulp pivot-row entry that then spread through a column
+// (tools/div_probe.hip counts such pairs).  The repair is exact: for a quotient q within one ulp
+// of a / b the residual a - q b is representable, so fma(-q, b, a) IS that residual; the same for
+// the neighbour of q on the side the residual points to; the smaller residual wins (a division
+// cannot produce an exact tie).  Outside the comfortable exponent range (zero, subnormal, huge,
+// inf, NaN) the hardware result is kept: the residuals would not be exact there.
+#if defined(__HIPCC__)
+// does the hardware quotient q of a / b need a second look?  (no: the residual is clearly -- by
+// 2^-20 of it -- below half an ulp of q times |b|.  Five instructions; one lane in a million says
+// yes; so do infinite and NaN quotients and those near the ends of the exponent range, where the
+// bound is meaningless: ieee_div_repair hands those back as they are.)
+__device__ __forceinline__ bool ieee_div_suspect(double a, double b, double q) {
+    const double r = __builtin_fma(-q, b, a);
+    // |b| * 2^(exponent of q - 54) * (1 - 2^-20): half an ulp of q times |b|, less a margin
+    const double h = __builtin_ldexp(b * 0x1.ffffep-1, __builtin_amdgcn_frexp_exp(q) - 54);
+    return !(__builtin_fabs(r) < __builtin_fabs(h));
+}
+__device__ __forceinline__ double ieee_div_repair(double a, double b, double q) {
+    const double aq = __builtin_fabs(q), aa = __builtin_fabs(a), ab = __builtin_fabs(b);
+    if (!(aq > 0x1p-900 && aq < 0x1p900 && aa > 0x1p-900 && aa < 0x1p900 && ab > 0x1p-900 &&
+          ab < 0x1p900))
+        return q;
+    const double r = __builtin_fma(-q, b, a);
+    if (r == 0.0) return q;
+    const long long qb = __builtin_bit_cast(long long, q);
+    const bool up = (r > 0.0) == (b > 0.0);  // a / b - q has the sign of r / b
+    const bool away = (q > 0.0) == up;       // the neighbour on that side is the larger magnitude
+    const double q2 = __builtin_bit_cast(double, qb + (away ? 1ll : -1ll));
+    const double r2 = __builtin_fma(-q2, b, a);
+    const double ar = __builtin_fabs(r), ar2 = __builtin_fabs(r2);
+    if (ar2 < ar || (ar2 == ar && (qb & 1ll))) return q2;
+    return q;
+}
+__device__ __forceinline__ double ieee_div(double a, double b) {
+    const double q = a / b;
+    if (__builtin_expect(ieee_div_suspect(a, b, q), 0)) return ieee_div_repair(a, b, q);
+    return q;
+}
+// N quotients behind ONE branch (the divisions and their checks interleave; a latency-bound loop
+// head pays for the branch, not for the seven instructions)
+template <int N>
+__device__ __forceinline__ void ieee_div_n(const double (&a)[N], const double (&b)[N],
+                                           double (&q)[N]) {
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        q[k] = a[k] / b[k];
+        any = any || ieee_div_suspect(a[k], b[k], q[k]);
+    }
+    if (__builtin_expect(any, 0)) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) q[k] = ieee_div_repair(a[k], b[k], q[k]);
+    }
+}
+#endif
+
 // Per-tableau control block in device memory.  Written by the select kernel, read by the update
 // kernel and polled by the host once per batch of pivots (never once per pivot).
 struct PivotState {

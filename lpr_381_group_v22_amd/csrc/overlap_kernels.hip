@@ -440,7 +440,7 @@ __device__ void ov_heads(const OvBuffers B, int ld, int R, int C, int Rp, int K,
                 // FindLeavingVariable (:169-191) on this lane's rows: its RHS entries are its own
                 if (i == 0) xst(&B.rparts[3 * kOvGroups], c);  // T[0, e], the Z row's factor
                 if (i >= 1 && c > 1e-9) {
-                    const double ratio = bprev[i] / c;
+                    const double ratio = ieee_div(bprev[i], c);
                     if (ratio >= 0 && ratio < rc.v) {
                         rc.v = ratio;
                         rc.i = i;
@@ -566,8 +566,8 @@ __device__ void ov_heads(const OvBuffers B, int ld, int R, int C, int Rp, int K,
                 }
                 const int j = 2 * c2;
                 double2 pq;
-                pq.x = (j < C) ? w.x / p : 0.0;  // :199 true division
-                pq.y = (j + 1 < C) ? w.y / p : 0.0;
+                pq.x = (j < C) ? ieee_div(w.x, p) : 0.0;  // :199 true division
+                pq.y = (j + 1 < C) ? ieee_div(w.y, p) : 0.0;
                 xst(&prowN[(size_t)(q - 1) * ld + 2 * c2], pq.x);
                 xst(&prowN[(size_t)(q - 1) * ld + 2 * c2 + 1], pq.y);
                 const double mxp = f0 * pq.x;  // :208 product rounded, then the difference
@@ -604,7 +604,7 @@ __device__ void ov_heads(const OvBuffers B, int ld, int R, int C, int Rp, int K,
                         wr = wr - prod;
                     }
                 }
-                lds_p[0] = wr / p;  // p was read by every lane before the arg-min barriers above
+                lds_p[0] = ieee_div(wr, p);  // p was read by every lane before the arg-min barriers above
             }
             __syncthreads();
             const double prhs = lds_p[0];
@@ -1022,7 +1022,7 @@ __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, i
             if (have_i) {
                 hst(&colq[i_first], cq, l2);
                 if (i_first >= 1 && cq > 1e-9) {
-                    const double ratio = myb / cq;
+                    const double ratio = ieee_div(myb, cq);
                     if (ratio >= 0 && ratio < DBL_MAX) {  // :184, minRatio starts at MaxValue
                         rc.v = ratio;
                         rc.i = i_first;
@@ -1057,7 +1057,7 @@ __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, i
                 }
                 hst(&colq[i], c, l2);
                 if (c > 1e-9) {
-                    const double ratio = bprev[i] / c;
+                    const double ratio = ieee_div(bprev[i], c);
                     if (ratio >= 0 && ratio < rc.v) {
                         rc.v = ratio;
                         rc.i = i;
@@ -1192,7 +1192,7 @@ __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, i
                     }
                 }
             }
-            const double prhs = wr / p;  // p_q[rhs]: every lane works it out for itself
+            const double prhs = ieee_div(wr, p);  // p_q[rhs]: every lane works it out for itself
             if (lane == q - 1) {
                 prhsNv = prhs;
                 rNv = r;
@@ -1204,8 +1204,8 @@ __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, i
             if (have_c) {
                 const int j = 2 * c2_first;
                 double2 pq;
-                pq.x = (j < C) ? w.x / p : 0.0;  // :199 true division
-                pq.y = (j + 1 < C) ? w.y / p : 0.0;
+                pq.x = (j < C) ? ieee_div(w.x, p) : 0.0;  // :199 true division
+                pq.y = (j + 1 < C) ? ieee_div(w.y, p) : 0.0;
 #pragma unroll
                 for (int t = 0; t < kOvMax; ++t)
                     if (t == q - 1) myp[t] = pq;
@@ -1262,8 +1262,8 @@ __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, i
                 }
                 const int j = 2 * c2;
                 double2 pq;
-                pq.x = (j < C) ? ww.x / p : 0.0;
-                pq.y = (j + 1 < C) ? ww.y / p : 0.0;
+                pq.x = (j < C) ? ieee_div(ww.x, p) : 0.0;
+                pq.y = (j + 1 < C) ? ieee_div(ww.y, p) : 0.0;
                 hst(&prowN[(size_t)(q - 1) * ld + j], pq.x, l2);
                 hst(&prowN[(size_t)(q - 1) * ld + j + 1], pq.y, l2);
                 const double mxp = f0 * pq.x;

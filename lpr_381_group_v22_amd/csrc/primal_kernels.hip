@@ -96,7 +96,7 @@ __global__ __launch_bounds__(1024) void k_select(double* __restrict__ T, int ld,
                 if (i < R) {
                     colbuf[i] = a[u];
                     if (i >= 1 && a[u] > 1e-9) {
-                        const double ratio = b[u] / a[u];  // IEEE division
+                        const double ratio = ieee_div(b[u], a[u]);  // IEEE division
                         if (ratio >= 0 && ratio < c.v) {
                             c.v = ratio;
                             c.i = i;
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(1024) void k_select(double* __restrict__ T, int ld,
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int j = j0 + u * nt;
-            if (j < ld) rowbuf[j] = (j < C) ? v[u] / p : 0.0;
+            if (j < ld) rowbuf[j] = (j < C) ? ieee_div(v[u], p) : 0.0;
         }
     }
     if (!gather_in_leave) {
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(1024) void k_pivot_head(const double* __restrict__ 
                 if (lead) colbuf[i] = a[u];
                 if (i == 0) lds_p[1] = a[u];
                 if (i >= 1 && a[u] > 1e-9) {
-                    const double ratio = b[u] / a[u];
+                    const double ratio = ieee_div(b[u], a[u]);
                     if (ratio >= 0 && ratio < c.v) {
                         c.v = ratio;
                         c.i = i;
@@ -352,8 +352,8 @@ __global__ __launch_bounds__(1024) void k_pivot_head(const double* __restrict__ 
         if (c2 != c2_first) zv = zrow2[c2];
         const int j = 2 * c2;
         double2 q;
-        q.x = (j < C) ? pv.x / p : 0.0;      // :199 true division
-        q.y = (j + 1 < C) ? pv.y / p : 0.0;
+        q.x = (j < C) ? ieee_div(pv.x, p) : 0.0;      // :199 true division
+        q.y = (j + 1 < C) ? ieee_div(pv.y, p) : 0.0;
         out2[c2] = q;
         const double mx = f0 * q.x;          // :208 product rounded ...
         const double my = f0 * q.y;
@@ -557,7 +557,7 @@ __global__ __launch_bounds__(256) void k_pivot_fused(const double* __restrict__ 
     for (int i = 1 + tid; i < R; i += nt) {
         const double a = Tin[(size_t)i * ld + e];
         if (a > 1e-9) {
-            const double ratio = Tin[(size_t)i * ld + rhs] / a;
+            const double ratio = ieee_div(Tin[(size_t)i * ld + rhs], a);
             if (ratio >= 0 && ratio < q.v) {
                 q.v = ratio;
                 q.i = i;
@@ -580,8 +580,8 @@ __global__ __launch_bounds__(256) void k_pivot_fused(const double* __restrict__ 
         double2* __restrict__ out2 = reinterpret_cast<double2*>(Tout);
         const double2 pv = in2[(size_t)r * ld2 + c2];
         double2 pr;
-        pr.x = (2 * c2 < C) ? pv.x / p : 0.0;      // :199 true division
-        pr.y = (2 * c2 + 1 < C) ? pv.y / p : 0.0;
+        pr.x = (2 * c2 < C) ? ieee_div(pv.x, p) : 0.0;      // :199 true division
+        pr.y = (2 * c2 + 1 < C) ? ieee_div(pv.y, p) : 0.0;
         double2 x[TR];
         double f[TR];
 #pragma unroll

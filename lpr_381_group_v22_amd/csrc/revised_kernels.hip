@@ -407,7 +407,7 @@ __global__ __launch_bounds__(256) void k_rev_snap_pre(const double* __restrict__
     }
     if (i >= m) return;
     const double ui = u[i];
-    ratios[i] = (ui > kEps) ? xB[i] / ui : (double)INFINITY;
+    ratios[i] = (ui > kEps) ? ieee_div(xB[i], ui) : (double)INFINITY;
     basis_pre[i] = basic[i];
 }
 

@@ -205,7 +205,7 @@ __device__ __forceinline__ void rev_ratio_body(const double* __restrict__ u,
 #pragma unroll
     for (int q = 0; q < kCacheR; ++q) {
         const int i = tid + q * nt;
-        rat[q] = (i < m && uu[q] > kRevEps) ? xx[q] / uu[q] : (double)NAN;
+        rat[q] = (i < m && uu[q] > kRevEps) ? ieee_div(xx[q], uu[q]) : (double)NAN;
         if (!(i < m)) bvi[q] = 0;
     }
     const bool cached_all = m <= kCacheR * nt;
@@ -302,7 +302,7 @@ __device__ __forceinline__ void rev_ratio_body(const double* __restrict__ u,
                 if (i <= cur) continue;
                 const double ui = rev_ld<SC1>(u + i);
                 if (!(ui > kRevEps)) continue;
-                const double ratio = rev_ld<SC1>(xB + i) / ui;
+                const double ratio = ieee_div(rev_ld<SC1>(xB + i), ui);
                 if (ratio < best - kRevEps ||
                     (fabs(ratio - best) <= kRevEps && (row == -1 || basic[i] < brow))) {
                     first = i;
@@ -318,7 +318,7 @@ __device__ __forceinline__ void rev_ratio_body(const double* __restrict__ u,
 #pragma unroll
             for (int q = 0; q < kCacheR; ++q)
                 if (tid + q * nt == first) v = rat[q];
-            if (first >= kCacheR * nt) v = rev_ld<SC1>(xB + first) / rev_ld<SC1>(u + first);
+            if (first >= kCacheR * nt) v = ieee_div(rev_ld<SC1>(xB + first), rev_ld<SC1>(u + first));
             lds_best = v;
         }
         __syncthreads();
@@ -358,12 +358,12 @@ __device__ __forceinline__ void rev_ratio_body(const double* __restrict__ u,
     for (int q = 0; q < kCacheR; ++q) {
         const int i = tid + q * nt;
         if (i < m) {
-            fac[i] = (i == row) ? 1.0 / pivot : -uu[q] / pivot;  // :272
+            fac[i] = (i == row) ? ieee_div(1.0, pivot) : ieee_div(-uu[q], pivot);  // :272
             browbuf[i] = Binv[(size_t)row * ldb + i];
         }
     }
     for (int i = tid + kCacheR * nt; i < m; i += nt) {
-        fac[i] = (i == row) ? 1.0 / pivot : -rev_ld<SC1>(u + i) / pivot;  // :272
+        fac[i] = (i == row) ? ieee_div(1.0, pivot) : ieee_div(-rev_ld<SC1>(u + i), pivot);  // :272
         browbuf[i] = Binv[(size_t)row * ldb + i];
     }
     for (int i = m + tid; i < ldb; i += nt) browbuf[i] = 0.0;

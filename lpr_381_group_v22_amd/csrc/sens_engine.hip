@@ -211,7 +211,7 @@ __global__ __launch_bounds__(1024) void k_sens_select(double* __restrict__ T, in
                 0, rhs, INFINITY,
                 [&](int j) {
                     const double a = lrow[j];
-                    return (a < -kSensEps) ? T[j] / (-a) : NAN;
+                    return (a < -kSensEps) ? ieee_div(T[j], -a) : NAN;
                 },
                 lds, lds_v);
             if (enter == -1) {
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(1024) void k_sens_select(double* __restrict__ T, in
             1, R, INFINITY,
             [&](int i) {
                 const double a = colbuf[i];
-                return (a > kSensEps) ? rhsd[i] / a : NAN;
+                return (a > kSensEps) ? ieee_div(rhsd[i], a) : NAN;
             },
             lds, lds_v);
         if (leave == -1) {
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(1024) void k_sens_select(double* __restrict__ T, in
         if (tid == 0) st->status = LPR_SENS_ZERO_PIVOT;  // :101
         return;
     }
-    for (int j = tid; j < ld; j += nt) rowbuf[j] = (j < C) ? T[(size_t)leave * ld + j] / piv : 0.0;
+    for (int j = tid; j < ld; j += nt) rowbuf[j] = (j < C) ? ieee_div(T[(size_t)leave * ld + j], piv) : 0.0;
     __syncthreads();
     if (tid == 0) {
         st->pr = leave;

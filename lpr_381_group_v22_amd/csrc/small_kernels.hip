@@ -169,10 +169,18 @@ struct SmallHead {
         Cand m;
         m.v = 0.0;
         m.i = -1;
+        double rnum[kNI], rden[kNI], rq[kNI];
+#pragma unroll
+        for (int u = 0; u < kNI; ++u) {  // (a lane without a candidate divides 0 by 1)
+            const bool cand = has_row[u] && row[u] >= 1 && x[u] > 1e-9;
+            rnum[u] = cand ? b[u] : 0.0;
+            rden[u] = cand ? x[u] : 1.0;
+        }
+        ieee_div_n<kNI>(rnum, rden, rq);
 #pragma unroll
         for (int u = 0; u < kNI; ++u) {
             if (has_row[u] && row[u] >= 1 && x[u] > 1e-9) {
-                const double ratio = b[u] / x[u];
+                const double ratio = rq[u];
                 if (ratio >= 0 && (m.i < 0 || ratio < m.v)) {  // rows ascend with u: ties keep the lower
                     m.v = ratio;
                     m.i = row[u];
@@ -229,10 +237,20 @@ struct SmallHead {
         stamp(Q, 6);
         const double piv = *s_piv;
         double2 p2[kNI];
+        {
+            double pn[2 * kNI], pd[2 * kNI], pq[2 * kNI];
+#pragma unroll
+            for (int u = 0; u < kNI; ++u) {
+                pn[2 * u] = y2[u].x;
+                pn[2 * u + 1] = y2[u].y;
+                pd[2 * u] = pd[2 * u + 1] = piv;
+            }
+            ieee_div_n<2 * kNI>(pn, pd, pq);
+#pragma unroll
+            for (int u = 0; u < kNI; ++u) p2[u] = make_double2(pq[2 * u], pq[2 * u + 1]);
+        }
 #pragma unroll
         for (int u = 0; u < kNI; ++u) {
-            p2[u].x = y2[u].x / piv;
-            p2[u].y = y2[u].y / piv;
             if (has_col[u] && (rhs >> 1) == cp[u]) *s_prhs2 = p2[u];
             if (has_col[u]) reinterpret_cast<double2*>(prow_g + (size_t)Q * ld)[cp[u]] = p2[u];
             if (has_row[u]) fcol_g[(size_t)Q * Rp + row[u]] = x[u];

@@ -340,3 +340,46 @@ def test_abi_argument_errors_are_statuses_not_crashes(engine):
     assert lib.lpr_comm_init_custom(0, 0, N.ALLREDUCE_MAX_FN(), N.ALLGATHER_FN(), None,
                                     C.byref(h)) == BAD
     assert lib.lpr_comm_destroy(None) == BAD and lib.lpr_comm_all_reduce_max(None, None, 1) == BAD
+
+
+# a / b whose exact quotient lies 2e-16 ulp from the midpoint of two doubles: the device's own fp64
+# division rounds it the other way (0.35 instead of 0.35000000000000003; tools/div_probe.hip)
+HARD_A, HARD_B = float.fromhex("0x1.6666666666663p+0"), float.fromhex("0x1.ffffffffffffbp+1")
+
+
+def _hard_division_tableau(rows=2, pad_cols=0):
+    """Z row [-1, 0, ..., 0]; row 1 = [b, a, ..., 1]: the first pivot is (1, 0) and normalises a / b
+    and 1 / b; further rows (factor 1 / 2) then carry the quotient on."""
+    C = 3 + pad_cols
+    T = np.zeros((rows, C))
+    T[0, 0] = -1.0
+    T[1, 0], T[1, 1], T[1, -1] = HARD_B, HARD_A, 1.0
+    for i in range(2, rows):
+        T[i, 0], T[i, 1], T[i, -1] = 0.5 * HARD_B, float(i), 10.0 * i
+    return T
+
+
+@pytest.mark.parametrize("rows,pad,variant,block", [(2, 0, 0, 0), (5, 3, 0, 0), (5, 3, 0x7fff, 1),
+                                                    (40, 70, 0x2008, 0), (40, 70, 0x4008, 4),
+                                                    (40, 70, 0x3008, 4), (40, 70, 0x6008, 4),
+                                                    (40, 70, 0x5008, 4)],
+                         ids=["2x3", "5x6", "5x6-graph", "small-heads", "seq", "ov2", "inplace",
+                              "ov"])
+def test_division_is_ieee_even_where_the_hardware_sequence_is_not(engine, oracle, rows, pad,
+                                                                  variant, block):
+    """Every `/` of the pivot loop (row normalisation :199, ratio test :180) goes through
+    ieee_div: the quotient of the hard pair must be the host's, whatever path runs."""
+    from lpr_381_group_v22_amd import Tableau
+    assert HARD_A / HARD_B == 0.35000000000000003
+    T0 = _hard_division_tableau(rows, pad)
+    T = T0.copy()
+    basis = np.arange(T.shape[1] - T.shape[0], T.shape[1] - 1, dtype=np.int32)
+    st, piv, log = oracle.primal_solve(T, basis, 1)
+    assert piv == 1 and T[1, 1] == 0.35000000000000003
+    tab = Tableau.from_array(engine, T0)
+    res = tab.solve(max_pivots=1, variant=variant, block=block)
+    assert res.pivots == 1
+    got = tab.read()
+    assert got[1, 1] == 0.35000000000000003
+    assert got.tobytes() == T.tobytes()
+    tab.destroy()

@@ -213,3 +213,22 @@ def test_full_size_resolve_properties(engine):
     else:
         assert rhs.tobytes() == rhs0.tobytes() and d.shape()[4] == z0
     d.destroy()
+
+
+def test_division_is_ieee_in_the_dual_pivot(engine, oracle):
+    """The pair tools/fuzz_side_gpu.py found (seed 170796): the normalised pivot row of a dual
+    pivot holds a / b with the exact quotient 2e-16 ulp from a midpoint; the hardware's division
+    sequence gives 0.35, IEEE (and the C#) 0.35000000000000003 (engine_common.hpp: ieee_div)."""
+    from lpr_381_group_v22_amd.engine import SensState
+    a, b = -float.fromhex("0x1.6666666666663p+0"), -float.fromhex("0x1.ffffffffffffbp+1")
+    T = np.array([[0.0, 1.0, 0.0, 0.0, 0.0],
+                  [b, a, 1.0, 0.0, -1.0],
+                  [0.5 * b, 2.0, 0.0, 1.0, 7.0]])
+    x = np.zeros(4)
+    o = oracle.sens(T, x, 0.0, np.zeros(2, dtype=np.int32))
+    d = SensState.create(engine, T, x, 0.0)
+    assert o.resolve_all() == d.resolve_all() == 0
+    assert o.log() == d.log() == [(0, 1, 0)]
+    assert o.state()["T"][1, 1] == 0.35000000000000003
+    _same_state(d, o, "hard division")
+    d.destroy()
