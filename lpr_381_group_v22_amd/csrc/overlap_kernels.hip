@@ -1192,7 +1192,14 @@ __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, i
                     }
                 }
             }
-            const double prhs = ieee_div(wr, p);  // p_q[rhs]: every lane works it out for itself
+            // p_q[rhs] (every lane works it out for itself) and this lane's pair of the normalised
+            // row (:199 true division): three quotients behind one check
+            double dq[3];
+            {
+                const double dn[3] = {wr, w.x, w.y}, dd[3] = {p, p, p};
+                ieee_div_n<3>(dn, dd, dq);
+            }
+            const double prhs = dq[0];
             if (lane == q - 1) {
                 prhsNv = prhs;
                 rNv = r;
@@ -1204,8 +1211,8 @@ __device__ void ov_heads_rich(const OvBuffers B, int ld, int R, int C, int Rp, i
             if (have_c) {
                 const int j = 2 * c2_first;
                 double2 pq;
-                pq.x = (j < C) ? ieee_div(w.x, p) : 0.0;  // :199 true division
-                pq.y = (j + 1 < C) ? ieee_div(w.y, p) : 0.0;
+                pq.x = (j < C) ? dq[1] : 0.0;
+                pq.y = (j + 1 < C) ? dq[2] : 0.0;
 #pragma unroll
                 for (int t = 0; t < kOvMax; ++t)
                     if (t == q - 1) myp[t] = pq;
