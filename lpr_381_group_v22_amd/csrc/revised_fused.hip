@@ -357,7 +357,9 @@ __global__ __launch_bounds__(64 * (NSW + 1)) void k_rev_rc_enter(
     // ---- the entering variable (:105-121) and its column (:149-151), by the last workgroup ----
     __threadfence_block();
     if (tid == 0) stamp_max(dbg, 2);
-    rev_enter_body<true, 32>(rcx, y, is_basic, n, m, st, At, ldb, Binv, ldb, acol, u, dbg, rev_ring,
+    // (a structural column is not copied out: k_rev_xu_ratio reads row e of At itself)
+    (void)acol;
+    rev_enter_body<true, 32>(rcx, y, is_basic, n, m, st, At, ldb, Binv, ldb, nullptr, u, dbg, rev_ring,
                              S * 32 * ROW);
     if (tid == 0) st->arrive_rc = 0;
     __syncthreads();
@@ -377,7 +379,7 @@ constexpr int kXuRC = 128;
 constexpr int kXuNSW = 8;   // stager waves (16 / kXuNSW rows each); the tail wants >= 512 threads at m = 4096
 __global__ __launch_bounds__(64 * (kXuNSW + 1)) void k_rev_xu_ratio(
     const double* __restrict__ Binv, int ld, int m, int n, const double* __restrict__ b,
-    double* __restrict__ xB, const double* __restrict__ acol, double* __restrict__ u,
+    double* __restrict__ xB, const double* __restrict__ At, double* __restrict__ u,
     int32_t* __restrict__ basic, uint8_t* __restrict__ is_basic, double* __restrict__ cB,
     const double* __restrict__ c, double* __restrict__ browbuf, double* __restrict__ fac,
     int32_t* __restrict__ log, RevState* st, unsigned long long* dbg) {
@@ -396,6 +398,8 @@ __global__ __launch_bounds__(64 * (kXuNSW + 1)) void k_rev_xu_ratio(
     __syncthreads();
     const int e = st->entering;
     const bool two = e >= 0 && e < n;   // slack: u = BInverse[:, k], written by the entering tail
+    // GetColumn(A, e) (:390-396) is row e of A transposed: contiguous, read in place
+    const double* __restrict__ acol = At + (size_t)(two ? e : 0) * ld;
     const int row0 = blockIdx.x * 16;
     const int nchunk = (m + RC - 1) / RC;
 
@@ -530,7 +534,7 @@ void rev_launch_xu_ratio(lpr_revised* s) {
     static unsigned long long asked = 0;
     raise_dyn_lds(&k_rev_xu_ratio, lds, asked);
     hipLaunchKernelGGL(k_rev_xu_ratio, dim3((s->m + 15) / 16), dim3(64 * (kXuNSW + 1)), lds,
-                       s->eng->stream, s->Binv, s->ldb, s->m, s->n, s->b, s->xB, s->acol, s->u,
+                       s->eng->stream, s->Binv, s->ldb, s->m, s->n, s->b, s->xB, s->At, s->u,
                        s->basic, s->is_basic, s->cB, s->c, s->browbuf, s->fac, s->log, s->state,
                        s->dbg_stamps);
 }

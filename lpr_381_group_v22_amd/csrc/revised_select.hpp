@@ -112,8 +112,11 @@ __device__ __forceinline__ void rev_enter_body(const double* __restrict__ rcx,
     // k_rev_ratio reports the optimum.
     if (cur < 0) return;
     if (cur < n) {
-        const double* __restrict__ src = At + (size_t)cur * ldt;
-        for (int i = tid; i < m; i += nt) acol[i] = src[i];
+        // (acol == nullptr: the caller's next kernel reads row `cur` of At itself -- the fused path)
+        if (acol) {
+            const double* __restrict__ src = At + (size_t)cur * ldt;
+            for (int i = tid; i < m; i += nt) acol[i] = src[i];
+        }
         return;
     }
     const double* __restrict__ src = Binv + (cur - n);
@@ -354,12 +357,23 @@ __device__ __forceinline__ void rev_ratio_body(const double* __restrict__ u,
         else st->iter = it + 1;  // :249
     }
     if (fabs(pivot) < kRevEps) return;
+    {   // the old pivot row of B^-1 is requested first, the kCacheR quotients share one check
+        double br[kCacheR], fn[kCacheR], fd[kCacheR], fq[kCacheR];
 #pragma unroll
-    for (int q = 0; q < kCacheR; ++q) {
-        const int i = tid + q * nt;
-        if (i < m) {
-            fac[i] = (i == row) ? ieee_div(1.0, pivot) : ieee_div(-uu[q], pivot);  // :272
-            browbuf[i] = Binv[(size_t)row * ldb + i];
+        for (int q = 0; q < kCacheR; ++q) {
+            const int i = tid + q * nt;
+            br[q] = Binv[(size_t)row * ldb + (i < m ? i : 0)];
+            fn[q] = (i == row) ? 1.0 : -uu[q];  // :272
+            fd[q] = pivot;
+        }
+        ieee_div_n<kCacheR>(fn, fd, fq);
+#pragma unroll
+        for (int q = 0; q < kCacheR; ++q) {
+            const int i = tid + q * nt;
+            if (i < m) {
+                fac[i] = fq[q];
+                browbuf[i] = br[q];
+            }
         }
     }
     for (int i = tid + kCacheR * nt; i < m; i += nt) {
