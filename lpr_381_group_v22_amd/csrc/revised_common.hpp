@@ -40,6 +40,9 @@ struct lpr_revised {
     double* xB = nullptr;       // m
     double* y = nullptr;        // m
     double* rcx = nullptr;      // n
+    double* wmin = nullptr;     // ceil(n/32) + ceil(m/16): per producing workgroup, the minimum of
+                                // -rc over its entering candidates (+inf: none), structural groups
+                                // first (k_rev_rc_enter), then slack groups (k_rev_update_y)
     double* acol = nullptr;     // m   GetColumn(A, e)
     double* u = nullptr;        // m   direction
     double* fac = nullptr;      // m   column r of E (:272)

@@ -29,6 +29,8 @@ static void rev_release_device(lpr_revised* s) {
     if (s->eng->stream) hipStreamSynchronize(s->eng->stream);
     hipFree(s->A); hipFree(s->At); hipFree(s->Binv); hipFree(s->b); hipFree(s->c); hipFree(s->cOrig);
     hipFree(s->cB); hipFree(s->xB); hipFree(s->y); hipFree(s->rcx); hipFree(s->acol);
+    hipFree(s->wmin);
+    s->wmin = nullptr;
     hipFree(s->u); hipFree(s->fac); hipFree(s->browbuf); hipFree(s->x); hipFree(s->z);
     hipFree(s->basic); hipFree(s->is_basic); hipFree(s->log); hipFree(s->state);
     hipFree(s->gemm_out);
@@ -82,6 +84,7 @@ static int rev_alloc(lpr_engine* e, int n, int m, int is_min, lpr_revised** out)
     chk(hipMalloc(&s->xB, (size_t)s->ldb * D));
     chk(hipMalloc(&s->y, (size_t)s->ldb * D));
     chk(hipMalloc(&s->rcx, (size_t)s->lda * D));
+    chk(hipMalloc(&s->wmin, (size_t)((n + 31) / 32 + (m + 15) / 16 + 1) * D));
     chk(hipMalloc(&s->acol, (size_t)s->ldb * D));
     chk(hipMalloc(&s->u, (size_t)s->ldb * D));
     chk(hipMalloc(&s->fac, (size_t)s->ldb * D));

@@ -141,7 +141,8 @@ template <int NSW, int NQ>
 __global__ __launch_bounds__(64 * (NSW + 1)) void k_rev_update_y(
     double* __restrict__ Binv, int ld, int m, const double* __restrict__ browbuf,
     const double* __restrict__ fac, const double* __restrict__ cB, double* __restrict__ y,
-    const RevState* __restrict__ st, int do_update) {
+    const RevState* __restrict__ st, int do_update, const uint8_t* __restrict__ is_basic, int n,
+    double* __restrict__ wmin_y) {
     constexpr int RC = NSW * 8 * NQ;
     constexpr int ROW = RC + kRingPad;
     constexpr int S = 3;  // ring slots
@@ -163,7 +164,19 @@ __global__ __launch_bounds__(64 * (NSW + 1)) void k_rev_update_y(
         // ---- the walker ----
         __builtin_amdgcn_s_setprio(3);
         const double s = ring_consume<RC, S, NSW, 16>(rev_ring, ctl, nchunk, m, lane, lane < 16);
-        if (lane < 16 && j0 + lane < m) y[j0 + lane] = s;
+        // slack k = n + j: rcS_k = -y_j (:100-102), a candidate when it is > EPS; the group's
+        // minimum of -rcS = y_j goes to the entering fold of the NEXT k_rev_rc_enter (rev_enter_hier)
+        double vmin = INFINITY;
+        if (lane < 16 && j0 + lane < m) {
+            y[j0 + lane] = s;
+            if (is_basic[n + j0 + lane] == 0 && -s > kRevEps) vmin = s;
+        }
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) {
+            const double o = __shfl_xor(vmin, off, kWave);
+            vmin = (o < vmin) ? o : vmin;
+        }
+        if (lane == 0) wmin_y[blockIdx.x] = vmin;
         return;
     }
 
@@ -277,7 +290,8 @@ __global__ __launch_bounds__(64 * (NSW + 1)) void k_rev_rc_enter(
     const double* __restrict__ A, int lda, int m, int n, const double* __restrict__ y,
     const double* __restrict__ c, double* __restrict__ rcx, const uint8_t* __restrict__ is_basic,
     const double* __restrict__ Binv, int ldb, double* __restrict__ acol, double* __restrict__ u,
-    RevState* st, unsigned long long* dbg, const double* __restrict__ At) {
+    RevState* st, unsigned long long* dbg, const double* __restrict__ At,
+    double* __restrict__ wmin) {
     constexpr int RC = NSW * 4 * NQ;
     constexpr int ROW = RC + kRingPad;
     constexpr int S = 4;
@@ -299,7 +313,18 @@ __global__ __launch_bounds__(64 * (NSW + 1)) void k_rev_rc_enter(
         __builtin_amdgcn_s_setprio(3);
         if (lane == 0) stamp_min(dbg, 0);
         const double s = ring_consume<RC, S, NSW, 32>(rev_ring, ctl, nchunk, m, lane, lane < 32);
-        if (lane < 32 && j0 + lane < n) st_sc1(rcx + j0 + lane, c[j0 + lane] - s);  // :97
+        double vmin = INFINITY;  // min of -rc over this workgroup's candidates (rev_enter_hier)
+        if (lane < 32 && j0 + lane < n) {
+            const double rc = c[j0 + lane] - s;  // :97
+            st_sc1(rcx + j0 + lane, rc);
+            if (is_basic[j0 + lane] == 0 && rc > kRevEps) vmin = -rc;
+        }
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) {
+            const double o = __shfl_xor(vmin, off, kWave);
+            vmin = (o < vmin) ? o : vmin;
+        }
+        if (lane == 0) st_sc1(wmin + blockIdx.x, vmin);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) stamp_max(dbg, 1);
         if (lane == 0 && arrive_is_last(&st->arrive_rc, (int)gridDim.x)) s_last = 1;
@@ -360,7 +385,7 @@ __global__ __launch_bounds__(64 * (NSW + 1)) void k_rev_rc_enter(
     // (a structural column is not copied out: k_rev_xu_ratio reads row e of At itself)
     (void)acol;
     rev_enter_body<true, 32>(rcx, y, is_basic, n, m, st, At, ldb, Binv, ldb, nullptr, u, dbg, rev_ring,
-                             S * 32 * ROW);
+                             S * 32 * ROW, wmin, (n + 31) / 32, (m + 15) / 16);
     if (tid == 0) st->arrive_rc = 0;
     __syncthreads();
     if (tid == 0) stamp_max(dbg, 3);
@@ -502,7 +527,7 @@ static void launch_update_y(lpr_revised* s, int do_update) {
     }
     hipLaunchKernelGGL((k_rev_update_y<NSW, NQ>), dim3((s->m + 15) / 16), dim3(64 * (NSW + 1)), lds,
                        s->eng->stream, s->Binv, s->ldb, s->m, s->browbuf, s->fac, s->cB, s->y,
-                       s->state, do_update);
+                       s->state, do_update, s->is_basic, s->n, s->wmin + (s->n + 31) / 32);
 }
 
 template <class K>
@@ -524,7 +549,7 @@ void rev_launch_rc_enter(lpr_revised* s) {
     raise_dyn_lds(&k_rev_rc_enter<NSW, NQ>, lds, asked);
     hipLaunchKernelGGL((k_rev_rc_enter<NSW, NQ>), dim3((s->n + 31) / 32), dim3(64 * (NSW + 1)), lds,
                        s->eng->stream, s->A, s->lda, s->m, s->n, s->y, s->c, s->rcx, s->is_basic,
-                       s->Binv, s->ldb, s->acol, s->u, s->state, s->dbg_stamps, s->At);
+                       s->Binv, s->ldb, s->acol, s->u, s->state, s->dbg_stamps, s->At, s->wmin);
 }
 
 // x_B and u in one pass over B^-1, then the ratio test and the bookkeeping of the pivot

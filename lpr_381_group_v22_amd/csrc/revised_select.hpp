@@ -40,6 +40,167 @@ __device__ __forceinline__ int block_min_int(int v, int* lds) {
 }
 
 // ------------------------------------------------------------------------------------------
+// The entering fold from GROUP MINIMA (the fused path).  The kernels that produce the reduced
+// costs leave, per group of consecutive candidates (32 structural columns of a k_rev_rc_enter
+// workgroup, 16 slack columns of a k_rev_update_y workgroup), the minimum of v = -rc over the
+// group's candidates (+inf: none).  A take of the C#'s fold is a strict prefix minimum of the whole
+// sequence (fold_common.hpp), i.e. a strict prefix minimum WITHIN its group that is also below
+// the minimum of every earlier group.  So: an exclusive prefix-min scan over the G group minima
+// (G = n/32 + m/16: 512 values instead of n + m = 12 288) gives each group its threshold; only the
+// ~ln G groups whose own minimum beats their threshold can hold a take; one wave reads just those
+// groups' values (two groups per 64 lanes, all loads of up to 16 groups requested before the
+// first is used) and replays the fold over their flagged lanes in index order.  Returns false
+// (nothing decided) when there are more groups than kHierPer per thread or more than kHierAct
+// active ones: the caller then runs the full fold.
+constexpr int kHierPer = 4;
+constexpr int kHierAct = 64;
+template <bool SC1>
+__device__ __forceinline__ bool rev_enter_hier(const double* __restrict__ wmin, int gr, int gy,
+                                               const double* __restrict__ rcx,
+                                               const double* __restrict__ y,
+                                               const uint8_t* __restrict__ is_basic, int n, int m,
+                                               int* cur_out, int* lds_i, double* lds_v) {
+    __shared__ int a_id[kHierAct];
+    __shared__ double a_thr[kHierAct];
+    __shared__ int s_res;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int lane = tid & (kWave - 1), wave = tid / kWave, nw = nt / kWave;
+    const int G = gr + gy;
+    if (G > kHierPer * nt) return false;  // (uniform)
+    const int cpt = (G + nt - 1) / nt;
+    const int g0 = tid * cpt;
+    double wm[kHierPer];
+#pragma unroll
+    for (int k = 0; k < kHierPer; ++k) {
+        const int g = g0 + k;
+        const bool ok = k < cpt && g < G;
+        const double t = rev_ld<SC1>(wmin + (ok ? g : 0));
+        wm[k] = (ok && t == t) ? t : (double)INFINITY;
+    }
+    double lmin = INFINITY;
+#pragma unroll
+    for (int k = 0; k < kHierPer; ++k) lmin = (wm[k] < lmin) ? wm[k] : lmin;
+    // exclusive prefix minimum of the per-thread minima over the block
+    __syncthreads();
+    double inc = lmin;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const double o = __shfl_up(inc, off, kWave);
+        if (lane >= off && o < inc) inc = o;
+    }
+    double exc = __shfl_up(inc, 1, kWave);
+    if (lane == 0) exc = INFINITY;
+    if (lane == kWave - 1) lds_v[wave] = inc;
+    __syncthreads();
+    {
+        const double wv = (lane < nw) ? lds_v[lane] : (double)INFINITY;
+        for (int w = 0; w < wave; ++w) {
+            const double x = readlane_f64(wv, w);
+            if (x < exc) exc = x;
+        }
+    }
+    // thresholds and active groups of this thread
+    unsigned act = 0;
+    double thr[kHierPer];
+    double run = exc;
+#pragma unroll
+    for (int k = 0; k < kHierPer; ++k) {
+        thr[k] = run;
+        if (wm[k] < run) {
+            act |= 1u << k;
+            run = wm[k];
+        }
+    }
+    // ordered compaction of the active groups
+    const int cnt = __popc(act);
+    int ci = cnt;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const int o = __shfl_up(ci, off, kWave);
+        if (lane >= off) ci += o;
+    }
+    if (lane == kWave - 1) lds_i[wave] = ci;
+    __syncthreads();
+    int before = 0, total = 0;
+    {
+        const int wt = (lane < nw) ? lds_i[lane] : 0;
+        for (int w = 0; w < nw; ++w) {
+            const int x = __builtin_amdgcn_readlane(wt, w);
+            if (w < wave) before += x;
+            total += x;
+        }
+    }
+    if (total > kHierAct) return false;  // (uniform)
+    {
+        int pos = before + ci - cnt;
+#pragma unroll
+        for (int k = 0; k < kHierPer; ++k) {
+            if ((act >> k) & 1u) {
+                a_id[pos] = g0 + k;
+                a_thr[pos] = thr[k];
+                ++pos;
+            }
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int half = lane >> 5, li = lane & 31;
+        double best = INFINITY;
+        int cur = -1;
+        constexpr int NB = 8;  // pairs of groups whose loads are in flight together
+        for (int b0 = 0; b0 < total; b0 += 2 * NB) {
+            double vv[NB], tt[NB];
+            int kk[NB];
+#pragma unroll
+            for (int p = 0; p < NB; ++p) {
+                const int a = b0 + 2 * p + half;
+                const bool have = a < total;
+                const int g = have ? a_id[a] : 0;
+                const bool xs = g < gr;
+                const int k = xs ? g * 32 + li : n + (g - gr) * 16 + li;
+                const bool ok = have && (xs ? k < n : (li < 16 && k < n + m));
+                const int kc = ok ? k : 0;
+                // one address, one load, selects afterwards (as cand_value of the full fold)
+                const double t = rev_ld<SC1>(kc < n ? rcx + kc : y + (kc - n));
+                const double rc = (kc < n) ? t : -t;  // rcS_k = -y_k (:100-102)
+                const bool cand = ok && is_basic[kc] == 0 && rc > kRevEps;
+                vv[p] = cand ? -rc : (double)NAN;
+                tt[p] = have ? a_thr[a] : 0.0;
+                kk[p] = k;
+            }
+#pragma unroll
+            for (int p = 0; p < NB; ++p) {
+                if (b0 + 2 * p >= total) break;  // (uniform)
+                // strict prefix minimum within the group (a 32-lane half), below its threshold
+                double pin = (vv[p] == vv[p]) ? vv[p] : (double)INFINITY;
+#pragma unroll
+                for (int off = 1; off < 32; off <<= 1) {
+                    const double o = __shfl_up(pin, off, 32);
+                    if (li >= off && o < pin) pin = o;
+                }
+                double pex = __shfl_up(pin, 1, 32);
+                if (li == 0) pex = INFINITY;
+                const bool flag = vv[p] < pex && vv[p] < tt[p];
+                const double x = flag ? vv[p] : (double)NAN;
+                unsigned long long alive = ~0ull;
+                for (;;) {
+                    const unsigned long long hit = __ballot(x < best - kFoldEps) & alive;
+                    if (hit == 0ull) break;
+                    const int fl = __builtin_amdgcn_readfirstlane(__builtin_ctzll(hit));
+                    best = readlane_f64(x, fl);
+                    cur = __builtin_amdgcn_readlane(kk[p], fl);
+                    alive = (fl == kWave - 1) ? 0ull : (~0ull << (fl + 1));
+                }
+            }
+        }
+        if (lane == 0) s_res = cur;
+    }
+    __syncthreads();
+    *cur_out = s_res;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------
 // Entering variable, RevisedPrimalSimplexSolver.cs:105-121:
 //     foreach vIdx in nonBasic ascending:  rc > EPS  and
 //         (none yet  or  rc > best + EPS  or  (|rc - best| <= EPS and vIdx < enteringIdx))  -> take
@@ -62,7 +223,9 @@ __device__ __forceinline__ void rev_enter_body(const double* __restrict__ rcx,
                                                const double* __restrict__ Binv, int ldb,
                                                double* __restrict__ acol, double* __restrict__ u,
                                                unsigned long long* dbg = nullptr,
-                                               double* s_val = nullptr, int s_cap = 0) {
+                                               double* s_val = nullptr, int s_cap = 0,
+                                               const double* __restrict__ wmin = nullptr,
+                                               int gr = 0, int gy = 0) {
     const int tid = threadIdx.x;
     const int nt = blockDim.x;
     // (the feasibility test of :90-91, "optimal" and the pivot limit are decided in k_rev_ratio,
@@ -84,7 +247,10 @@ __device__ __forceinline__ void rev_enter_body(const double* __restrict__ rcx,
         return cand ? -rc : (double)NAN;
     };
     int cur;
-    if (s_val != nullptr && N <= s_cap) {
+    if (wmin != nullptr && rev_enter_hier<SC1>(wmin, gr, gy, rcx, y, is_basic, n, m, &cur, lds_i2,
+                                               lds_v2)) {
+        // (decided from the group minima the producing kernels left)
+    } else if (s_val != nullptr && N <= s_cap) {
         constexpr int G = 8;
         for (int k0 = tid; k0 < N; k0 += G * nt) {
             double t[G];
