@@ -270,6 +270,11 @@ int lpr_revised_solve(lpr_revised* s, const lpr_solve_opts* opts, lpr_revised_re
             unsigned long long t[16];
             LPR_HIP(hipStreamSynchronize(st));
             LPR_HIP(hipMemcpy(t, s->dbg_stamps, sizeof t, hipMemcpyDeviceToHost));
+            std::fprintf(stderr, "xu walker of workgroup 100: chunks 8..24 (2048 adds per output) %.2f us = "
+                         "%.2f ns per add; entered %.2f us after the kernel's first workgroup\n",
+                         (double)((long long)(t[13] - t[12])) * 0.01,
+                         (double)((long long)(t[13] - t[12])) * 10.0 / 2048.0,
+                         (double)((long long)(t[12] - t[4])) * 0.01);
             std::fprintf(stderr, "rev stamps (us): rc walk %.2f, to tail %.2f, enter tail %.2f | xu walk "
                          "%.2f, to tail %.2f, ratio tail %.2f | rc start -> xu start %.2f | enter: fold "
                          "%.2f gather %.2f | ratio: loads+exits %.2f replay %.2f rest %.2f\n",

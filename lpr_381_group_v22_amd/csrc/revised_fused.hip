@@ -102,7 +102,8 @@ struct RingWalker {
 // The walker wave's loop over the chunks of one output per lane.  NOUT rows per slot.
 template <int RC, int S, int NSW, int NOUT>
 __device__ __forceinline__ double ring_consume(const double* ring, RingCtl& ctl, int nchunk,
-                                               int total, int lane, bool mine) {
+                                               int total, int lane, bool mine,
+                                               unsigned long long* wdbg = nullptr) {
     constexpr int ROW = RC + kRingPad;
     RingWalker<RC> wk;
     double s = 0.0;
@@ -112,6 +113,8 @@ __device__ __forceinline__ double ring_consume(const double* ring, RingCtl& ctl,
     };
     if (nchunk > 0) wait_ready(0);
     for (int ch = 0; ch < nchunk; ++ch) {
+        if (wdbg && lane == 0 && (ch == 8 || ch == 24))  // diagnostic: 16 chunks of one walker
+            wdbg[ch == 8 ? 0 : 1] = __builtin_amdgcn_s_memrealtime();
         if (ch + 1 < nchunk) wait_ready(ch + 1);
         asm volatile("" ::: "memory");
         if (mine) {
@@ -149,16 +152,41 @@ __global__ __launch_bounds__(64 * (NSW + 1)) void k_rev_update_y(
     static_assert(RC % 32 == 0, "bank spreading assumes RC % 32 == 0");
     extern __shared__ __attribute__((aligned(16))) double rev_ring[];  // [S][16][ROW]
     __shared__ RingCtl ctl;
-    if (st->status != kRunning) return;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
+    const int j0 = blockIdx.x * 16;
+    const int nchunk = (m + RC - 1) / RC;
+    const int ld2 = ld >> 1;
+    // the stagers' first chunk is requested BEFORE the control block is looked at (k_rev_xu_ratio)
+    const int w = wave - 1;
+    const int cp = lane & 7;       // column pair of the strip
+    const int rs = lane >> 3;      // row of a wave-instruction
+    const int c2 = (j0 >> 1) + cp;
+    const bool col_ok = c2 < ld2;
+    double2* __restrict__ B2 = reinterpret_cast<double2*>(Binv);
+    double2 x[NQ], xn[NQ];
+    double f[NQ], fn[NQ], cb[NQ], cbn[NQ];
+    auto load_chunk = [&](int c, double2 (&xx)[NQ], double (&ff)[NQ], double (&cc)[NQ]) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int i = c * RC + (q * NSW + w) * 8 + rs;
+            const bool ok = i < m && col_ok;
+            xx[q] = ok ? B2[(size_t)i * ld2 + c2] : make_double2(0.0, 0.0);
+            ff[q] = (ok && do_update) ? fac[i] : 0.0;
+            cc[q] = ok ? cB[i] : 0.0;
+        }
+    };
+    double2 br = make_double2(0.0, 0.0);
+    if (wave != 0) {
+        load_chunk(0, x, f, cb);
+        if (do_update && col_ok) br = reinterpret_cast<const double2*>(browbuf)[c2];
+    }
+    const int32_t status0 = st->status;
+    const int r = do_update ? st->leaving_row : -1;
+    if (status0 != kRunning) return;
     if (tid < 4) ctl.ready[tid] = 0;
     if (tid == 4) ctl.done = 0;
     __syncthreads();
-    const int j0 = blockIdx.x * 16;
-    const int nchunk = (m + RC - 1) / RC;
-    const int r = do_update ? st->leaving_row : -1;
-    const int ld2 = ld >> 1;
 
     if (wave == 0) {
         // ---- the walker ----
@@ -181,27 +209,6 @@ __global__ __launch_bounds__(64 * (NSW + 1)) void k_rev_update_y(
     }
 
     // ---- the stagers ----
-    const int w = wave - 1;
-    const int cp = lane & 7;       // column pair of the strip
-    const int rs = lane >> 3;      // row of a wave-instruction
-    const int c2 = (j0 >> 1) + cp;
-    const bool col_ok = c2 < ld2;
-    double2* __restrict__ B2 = reinterpret_cast<double2*>(Binv);
-    const double2 br = (do_update && col_ok) ? reinterpret_cast<const double2*>(browbuf)[c2]
-                                             : make_double2(0.0, 0.0);
-    double2 x[NQ], xn[NQ];
-    double f[NQ], fn[NQ], cb[NQ], cbn[NQ];
-    auto load_chunk = [&](int c, double2 (&xx)[NQ], double (&ff)[NQ], double (&cc)[NQ]) {
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int i = c * RC + (q * NSW + w) * 8 + rs;
-            const bool ok = i < m && col_ok;
-            xx[q] = ok ? B2[(size_t)i * ld2 + c2] : make_double2(0.0, 0.0);
-            ff[q] = (ok && do_update) ? fac[i] : 0.0;
-            cc[q] = ok ? cB[i] : 0.0;
-        }
-    };
-    load_chunk(0, x, f, cb);
     for (int c = 0; c < nchunk; ++c) {
         if (c + 1 < nchunk) load_chunk(c + 1, xn, fn, cbn);  // in flight under this chunk's work
         const int slot = c % S;
@@ -299,15 +306,39 @@ __global__ __launch_bounds__(64 * (NSW + 1)) void k_rev_rc_enter(
     extern __shared__ __attribute__((aligned(16))) double rev_ring[];  // [S][32][ROW]
     __shared__ RingCtl ctl;
     __shared__ int s_last;
-    if (st->status != kRunning) return;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
+    const int j0 = blockIdx.x * 32;
+    const int nchunk = (m + RC - 1) / RC;
+    // the stagers' first two chunks are requested BEFORE the control block is looked at
+    // (k_rev_xu_ratio)
+    const int w = wave - 1;
+    const int cp = lane & 15;   // column pair of the strip
+    const int rs = lane >> 4;   // row of a wave-instruction
+    const int col = j0 + 2 * cp;
+    const bool col_ok = col < lda;
+    rv2d_t xb[3][NQ];
+    double yb[3][NQ];
+    auto load_chunk = [&](int ch, rv2d_t (&xx)[NQ], double (&yy)[NQ]) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int i = ch * RC + (q * NSW + w) * 4 + rs;
+            const bool ok = i < m && col_ok && ch < nchunk;
+            xx[q] = ok ? __builtin_nontemporal_load(
+                             reinterpret_cast<const rv2d_t*>(A + (size_t)i * lda + col))
+                       : (rv2d_t){0.0, 0.0};
+            yy[q] = ok ? y[i] : 0.0;
+        }
+    };
+    if (wave != 0) {
+        load_chunk(0, xb[0], yb[0]);
+        load_chunk(1, xb[1], yb[1]);
+    }
+    if (st->status != kRunning) return;
     if (tid < 4) ctl.ready[tid] = 0;
     if (tid == 4) ctl.done = 0;
     if (tid == 5) s_last = 0;
     __syncthreads();
-    const int j0 = blockIdx.x * 32;
-    const int nchunk = (m + RC - 1) / RC;
 
     if (wave == 0) {
         __builtin_amdgcn_s_setprio(3);
@@ -329,24 +360,6 @@ __global__ __launch_bounds__(64 * (NSW + 1)) void k_rev_rc_enter(
         if (lane == 0) stamp_max(dbg, 1);
         if (lane == 0 && arrive_is_last(&st->arrive_rc, (int)gridDim.x)) s_last = 1;
     } else {
-        const int w = wave - 1;
-        const int cp = lane & 15;   // column pair of the strip
-        const int rs = lane >> 4;   // row of a wave-instruction
-        const int col = j0 + 2 * cp;
-        const bool col_ok = col < lda;
-        rv2d_t xb[3][NQ];
-        double yb[3][NQ];
-        auto load_chunk = [&](int ch, rv2d_t (&xx)[NQ], double (&yy)[NQ]) {
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const int i = ch * RC + (q * NSW + w) * 4 + rs;
-                const bool ok = i < m && col_ok && ch < nchunk;
-                xx[q] = ok ? __builtin_nontemporal_load(
-                                 reinterpret_cast<const rv2d_t*>(A + (size_t)i * lda + col))
-                           : (rv2d_t){0.0, 0.0};
-                yy[q] = ok ? y[i] : 0.0;
-            }
-        };
         auto fill = [&](int ch, const rv2d_t (&xx)[NQ], const double (&yy)[NQ]) {
             const int slot = ch % S;
             while (lds_load(&ctl.done) < ch - S + 1) __builtin_amdgcn_s_sleep(1);
@@ -362,8 +375,6 @@ __global__ __launch_bounds__(64 * (NSW + 1)) void k_rev_rc_enter(
             if (lane == 0) __hip_atomic_fetch_add(&ctl.ready[slot], 1, __ATOMIC_RELAXED,
                                                   __HIP_MEMORY_SCOPE_WORKGROUP);
         };
-        load_chunk(0, xb[0], yb[0]);
-        load_chunk(1, xb[1], yb[1]);
         for (int ch = 0; ch < nchunk; ch += 3) {   // register sets rotate with the chunk number
             load_chunk(ch + 2, xb[2], yb[2]);
             fill(ch, xb[0], yb[0]);
@@ -414,25 +425,58 @@ __global__ __launch_bounds__(64 * (kXuNSW + 1)) void k_rev_xu_ratio(
     extern __shared__ __attribute__((aligned(16))) double rev_ring[];  // [S][32][ROW]
     __shared__ RingCtl ctl;
     __shared__ int s_last;
-    if (st->status != kRunning) return;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
+    const int row0 = blockIdx.x * 16;
+    const int nchunk = (m + RC - 1) / RC;
+    constexpr int RPW = 16 / NSW;   // rows a stager wave stages: w * RPW ...
+    struct Regs {
+        double2 r[RPW];   // columns k0 + 2 lane, + 1 of those rows
+        double2 bv, av;
+    };
+    constexpr int D = 4;   // chunks the loads run ahead of the ring fill (D + 1 register sets)
+    Regs rg[D + 1];
+    const int ld2 = ld >> 1;
+    const double2* __restrict__ B2 = reinterpret_cast<const double2*>(Binv);
+    // B^-1 and b of a chunk (nothing here depends on the control block)
+    auto load_chunk_b = [&](int ch, Regs& g) {
+        const int w = wave - 1;
+        const int k = ch * RC + 2 * lane;   // first of this lane's two columns
+        const bool ok = ch < nchunk && k < ld;
+        const double2 z = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int q = 0; q < RPW; ++q) {
+            const int i = row0 + w * RPW + q;
+            g.r[q] = (ok && i < m) ? B2[(size_t)i * ld2 + (k >> 1)] : z;
+        }
+        g.bv.x = (ok && k < m) ? b[k] : 0.0;
+        g.bv.y = (ok && k + 1 < m) ? b[k + 1] : 0.0;
+        g.av = z;
+    };
+    // The stagers ask for their first D chunks BEFORE the control block is looked at: the status /
+    // entering words are a memory round trip of their own (~1.5 us with every CU starting up at
+    // once) and the chain cannot start before the first chunk is in the ring.
+    if (wave != 0) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) load_chunk_b(k, rg[k]);
+    }
+    const int32_t status0 = st->status;
+    const int e = st->entering;
+    if (status0 != kRunning) return;
     if (tid < 4) ctl.ready[tid] = 0;
     if (tid == 4) ctl.done = 0;
     if (tid == 5) s_last = 0;
     __syncthreads();
-    const int e = st->entering;
     const bool two = e >= 0 && e < n;   // slack: u = BInverse[:, k], written by the entering tail
     // GetColumn(A, e) (:390-396) is row e of A transposed: contiguous, read in place
     const double* __restrict__ acol = At + (size_t)(two ? e : 0) * ld;
-    const int row0 = blockIdx.x * 16;
-    const int nchunk = (m + RC - 1) / RC;
 
     if (wave == 0) {
         __builtin_amdgcn_s_setprio(3);
         if (lane == 0) stamp_min(dbg, 4);
         const bool mine = lane < 16 || (two && lane < 32);
-        const double s = ring_consume<RC, S, NSW, 32>(rev_ring, ctl, nchunk, m, lane, mine);
+        const double s = ring_consume<RC, S, NSW, 32>(rev_ring, ctl, nchunk, m, lane, mine,
+                                                      (dbg && blockIdx.x == 100) ? dbg + 12 : nullptr);
         if (lane < 16 && row0 + lane < m) st_sc1(xB + row0 + lane, s);
         if (two && lane >= 16 && lane < 32 && row0 + lane - 16 < m) st_sc1(u + row0 + lane - 16, s);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -440,31 +484,17 @@ __global__ __launch_bounds__(64 * (kXuNSW + 1)) void k_rev_xu_ratio(
         if (lane == 0 && arrive_is_last(&st->arrive_xu, (int)gridDim.x)) s_last = 1;
     } else {
         const int w = wave - 1;
-        constexpr int RPW = 16 / NSW;   // rows a stager wave stages: w * RPW ...
-        struct Regs {
-            double2 r[RPW];   // columns k0 + 2 lane, + 1 of those rows
-            double2 bv, av;
-        };
-        constexpr int D = 4;   // chunks the loads run ahead of the ring fill (D + 1 register sets)
-        Regs rg[D + 1];
-        const int ld2 = ld >> 1;
-        const double2* __restrict__ B2 = reinterpret_cast<const double2*>(Binv);
-        auto load_chunk = [&](int ch, Regs& g) {
-            const int k = ch * RC + 2 * lane;   // first of this lane's two columns
+        auto load_chunk_a = [&](int ch, Regs& g) {   // a_e of a chunk (needs the entering variable)
+            const int k = ch * RC + 2 * lane;
             const bool ok = ch < nchunk && k < ld;
-            const double2 z = make_double2(0.0, 0.0);
-#pragma unroll
-            for (int q = 0; q < RPW; ++q) {
-                const int i = row0 + w * RPW + q;
-                g.r[q] = (ok && i < m) ? B2[(size_t)i * ld2 + (k >> 1)] : z;
-            }
-            g.bv.x = (ok && k < m) ? b[k] : 0.0;
-            g.bv.y = (ok && k + 1 < m) ? b[k + 1] : 0.0;
-            g.av = z;
             if (two) {
                 g.av.x = (ok && k < m) ? acol[k] : 0.0;
                 g.av.y = (ok && k + 1 < m) ? acol[k + 1] : 0.0;
             }
+        };
+        auto load_chunk = [&](int ch, Regs& g) {
+            load_chunk_b(ch, g);
+            load_chunk_a(ch, g);
         };
         auto fill = [&](int ch, const Regs& g) {
             const int slot = ch % S;
@@ -487,7 +517,7 @@ __global__ __launch_bounds__(64 * (kXuNSW + 1)) void k_rev_xu_ratio(
                                                   __HIP_MEMORY_SCOPE_WORKGROUP);
         };
 #pragma unroll
-        for (int k = 0; k < D; ++k) load_chunk(k, rg[k]);
+        for (int k = 0; k < D; ++k) load_chunk_a(k, rg[k]);   // (B^-1 and b were requested at the top)
         for (int ch = 0; ch < nchunk; ch += D + 1) {  // register sets rotate with the chunk number
 #pragma unroll
             for (int k = 0; k <= D; ++k) {
