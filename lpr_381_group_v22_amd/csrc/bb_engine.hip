@@ -34,7 +34,6 @@ void bb_launch_add_constraint(lpr_bb* b, int nslots, int nparents, int rows_max,
 void bb_launch_pivot_step(lpr_bb* b, int nslots, int rows_max, int cols_max, int step_no);
 void bb_launch_finish(lpr_bb* b, int nslots, int cols_max);
 void bb_launch_gather_info(lpr_bb* b, int count);
-void bb_launch_select_only(lpr_bb* b, int nslots, int rows_max, int cols_max);
 
 // ---- .NET Framework rounding on the host (IsInteger :595-599 works on n values per node) ----
 static double dn_round_int(double x) {  // Math.Round(double), COMDouble::Round

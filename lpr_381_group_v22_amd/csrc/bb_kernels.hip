@@ -867,11 +867,4 @@ void bb_launch_pivot_step(lpr_bb* b, int nslots, int rows_max, int cols_max, int
                        b->d_slots, b->rowbuf, b->colbuf, b->rowlist, b->ld, b->rows_cap);
 }
 
-void bb_launch_select_only(lpr_bb* b, int nslots, int rows_max, int cols_max) {
-    const int threads = (rows_max > 256 || cols_max > 256) ? 1024 : 256;
-    hipLaunchKernelGGL(k_bb_select, dim3(nslots), dim3(threads), 0, b->eng->stream, b->d_slots,
-                       b->rowbuf, b->colbuf, b->ld, b->rows_cap, b->trace, b->trace_cap,
-                       b->d_running, 0, b->rowlist, b->touched, align_up(b->rows_cap, 16));
-}
-
 }  // namespace lpr

@@ -296,9 +296,8 @@ template <int NSW, int NQ>
 __global__ __launch_bounds__(64 * (NSW + 1)) void k_rev_rc_enter(
     const double* __restrict__ A, int lda, int m, int n, const double* __restrict__ y,
     const double* __restrict__ c, double* __restrict__ rcx, const uint8_t* __restrict__ is_basic,
-    const double* __restrict__ Binv, int ldb, double* __restrict__ acol, double* __restrict__ u,
-    RevState* st, unsigned long long* dbg, const double* __restrict__ At,
-    double* __restrict__ wmin) {
+    const double* __restrict__ Binv, int ldb, double* __restrict__ u, RevState* st,
+    unsigned long long* dbg, const double* __restrict__ At, double* __restrict__ wmin) {
     constexpr int RC = NSW * 4 * NQ;
     constexpr int ROW = RC + kRingPad;
     constexpr int S = 4;
@@ -394,7 +393,6 @@ __global__ __launch_bounds__(64 * (NSW + 1)) void k_rev_rc_enter(
     __threadfence_block();
     if (tid == 0) stamp_max(dbg, 2);
     // (a structural column is not copied out: k_rev_xu_ratio reads row e of At itself)
-    (void)acol;
     rev_enter_body<true, 32>(rcx, y, is_basic, n, m, st, At, ldb, Binv, ldb, nullptr, u, dbg, rev_ring,
                              S * 32 * ROW, wmin, (n + 31) / 32, (m + 15) / 16);
     if (tid == 0) st->arrive_rc = 0;
@@ -579,7 +577,7 @@ void rev_launch_rc_enter(lpr_revised* s) {
     raise_dyn_lds(&k_rev_rc_enter<NSW, NQ>, lds, asked);
     hipLaunchKernelGGL((k_rev_rc_enter<NSW, NQ>), dim3((s->n + 31) / 32), dim3(64 * (NSW + 1)), lds,
                        s->eng->stream, s->A, s->lda, s->m, s->n, s->y, s->c, s->rcx, s->is_basic,
-                       s->Binv, s->ldb, s->acol, s->u, s->state, s->dbg_stamps, s->At, s->wmin);
+                       s->Binv, s->ldb, s->u, s->state, s->dbg_stamps, s->At, s->wmin);
 }
 
 // x_B and u in one pass over B^-1, then the ratio test and the bookkeeping of the pivot
