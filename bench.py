@@ -257,7 +257,7 @@ def run_primal(args, D: Dist):
                                  "tableau stays in L2 / Infinity Cache)",
                          "us_per_pivot": round(1e6 * D.world / value, 3)})
             if B > 1 and R <= 1024 and (C + 15) // 16 * 16 <= 2048 and args.variant == 0 \
-                    and args.block == 0 and R * ((C + 15) // 16 * 16) * 8 <= (10 << 20):
+                    and args.block == 0:
                 roof["kernel"] = ("k_small_heads (the 16 loop heads of a block in one workgroup) "
                                   "+ k_small_sweep (in place)")
         roof.update(_pmc_traffic(m, n, B))

@@ -379,15 +379,16 @@ static int solve_fused(lpr_tableau* t, const lpr_solve_opts& o, lpr_solve_result
 // Cache-resident tableaux (R <= 1024, ld <= 2048: small_kernels.hip): the 16 loop heads of a block
 // in ONE workgroup, hand-offs through LDS, then one in-place sweep.  The default for every tableau
 // that fits (opts.variant == 0, opts.block == 0); opts.variant 0x20xx forces it.
-// Measured (bench.py, pivots/s, this path vs heads-then-sweep 0x4008): m = 512 (6.3 MB) 176 k vs
-// 154 k; m = n = 1000 (16 MB) 132 k vs 140 k -- the single workgroup's two gathers per pivot grow
-// with the tableau, so the default stops at kSmallBytes.
-static constexpr size_t kSmallBytes = (size_t)10 << 20;
+// Measured on the round's final code (tools/size_sweep.sh, profiles/r03_size_sweep.jsonl; pivots/s,
+// this path vs heads-then-sweep 0x4008): m = 512 (6.3 MB) 214 k vs 154 k; 640 x 1280 (9.9 MB) 206 k
+// vs 150 k; 1020 x 400 (11.6 MB) 194 k vs 110 k; 800 x 1200 (12.8 MB) 193 k vs 145 k; m = n = 1000
+// (16 MB) 184 k vs 146 k; 1023 x 1000 (16.6 MB, the largest that fits) 183 k vs 146 k: it wins
+// wherever it fits.  (Mid round 3 the 16 MB case read 132 k vs 140 k and the default stopped at
+// 10 MB; the later work on the heads moved it.)
 static bool use_small(const lpr_tableau* t, const lpr_solve_opts& o) {
     if (!small_fits(t)) return false;
     if ((o.variant & 0xff00) == 0x2000) return true;
-    return o.variant == 0 && o.block == 0 &&
-           (size_t)t->rows * t->ld * sizeof(double) <= kSmallBytes;
+    return o.variant == 0 && o.block == 0;
 }
 
 static int solve_small(lpr_tableau* t, const lpr_solve_opts& o, lpr_solve_result* res) {

@@ -531,7 +531,7 @@ def test_pivot_log_growth_is_crossed_in_an_oracle_checked_solve(engine, oracle, 
     tab2.destroy()
 
 
-SMALL = 0x2000  # csrc/small_kernels.hip forced (the default up to 10 MB)
+SMALL = 0x2000  # csrc/small_kernels.hip forced (the default wherever it fits: R <= 1024, ld <= 2048)
 
 
 @pytest.mark.parametrize("m,n,pivots", [(1023, 1000, 90), (1000, 1000, 120), (700, 1300, 200),
