@@ -39,6 +39,8 @@ struct BBSlot {
     int32_t big;       // set by k_bb_round: a rounded entry is >= 1e11 or not finite
     double bound;
     const double* parent;  // parent node's (rounded) tableau, (rows-1) x (cols-1)
+    int32_t inplace;   // 1: this child takes its parent's buffer over (cur == parent): k_bb_child_init
+                       // leaves it alone, k_bb_child_inplace turns the parent into the child
     int32_t pscan;     // row of bflag / bkey holding this child's PARENT's basic-column scan
     int32_t rep;       // slots[u].rep: a child slot of the u-th distinct parent of the batch
 };

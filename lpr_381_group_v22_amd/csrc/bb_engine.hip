@@ -30,7 +30,7 @@ void bb_launch_copy_in(lpr_bb* b, const double* src, int src_ld, int rows, int c
 void bb_launch_round(lpr_bb* b, int nslots, int rows_max, int clean);
 void bb_launch_node_info(lpr_bb* b, int count);
 void bb_launch_add_constraint(lpr_bb* b, int nslots, int nparents, int rows_max, int cols_max,
-                              bool side);
+                              bool side, bool inplace);
 void bb_launch_pivot_step(lpr_bb* b, int nslots, int rows_max, int cols_max, int step_no);
 void bb_launch_finish(lpr_bb* b, int nslots, int cols_max);
 void bb_launch_gather_info(lpr_bb* b, int count);
@@ -268,7 +268,13 @@ static int bb_expand(lpr_bb* b, int count, const int32_t* parent_ids, const int3
                      const double* bound, const int32_t* kind, int32_t* child_ids_out,
                      int32_t* status_out, int32_t* pivots_out,
                      std::vector<int32_t>* trace_out /* triples per child, flattened */,
-                     std::vector<int32_t>* trace_off, BBKeep* keep = nullptr) {
+                     std::vector<int32_t>* trace_off, BBKeep* keep = nullptr,
+                     bool consume = false) {
+    // consume: the caller releases every parent right after this call (the tree drivers do).  The
+    // SECOND of two consecutive children of one parent then takes the parent's buffer over instead
+    // of copying it (k_bb_child_inplace): half of k_bb_child_init's traffic, the largest single
+    // item of a level.  Only for parents that carry their own scan and were rounded below 1e11
+    // (`side`, not `big`): their stored rows are what a child starts from, up to the sign of zeros.
     if (count <= 0) return LPR_OK_OPTIMAL;
     int rc = bb_ensure_slots(b, count);
     if (rc != LPR_OK_OPTIMAL) return rc;
@@ -314,16 +320,31 @@ static int bb_expand(lpr_bb* b, int count, const int32_t* parent_ids, const int3
         rows_max = s.rows > rows_max ? s.rows : rows_max;
         cols_max = s.cols > cols_max ? s.cols : cols_max;
     }
+    bool side = true;  // every parent carries its own IdentifyBasicVariables scan
+    for (int k = 0; k < count; ++k)
+        side = side && b->nodes[parent_ids[k]].side && !b->nodes[parent_ids[k]].big;
+    bool any_inplace = false;
+    if (consume && side && !keep) {
+        for (int k = 1; k < count; ++k) {
+            const int pid = parent_ids[k];
+            if (pid != parent_ids[k - 1] || b->h_slots[k - 1].inplace) continue;
+            if (k + 1 < count && parent_ids[k + 1] == pid) continue;  // (not a pair: leave it)
+            BBSlot& s = b->h_slots[k];
+            b->free_bufs.push_back(s.cur);   // the buffer set aside for it above is not needed
+            s.cur = b->nodes[pid].T;
+            s.inplace = 1;
+            b->nodes[pid].live = false;      // the child owns the buffer from here on
+            b->nodes[pid].T = nullptr;
+            any_inplace = true;
+        }
+    }
     LPR_HIP(hipMemcpyAsync(b->d_slots, b->h_slots, (size_t)count * sizeof(BBSlot),
                            hipMemcpyHostToDevice, st));
     b->h_running[0] = count;
     b->h_running[1] = 0;
     LPR_HIP(hipMemcpyAsync(b->d_running, b->h_running, 2 * sizeof(int32_t), hipMemcpyHostToDevice,
                            st));
-    bool side = true;  // every parent carries its own IdentifyBasicVariables scan
-    for (int k = 0; k < count; ++k)
-        side = side && b->nodes[parent_ids[k]].side && !b->nodes[parent_ids[k]].big;
-    bb_launch_add_constraint(b, count, nparents, rows_max, cols_max, side);
+    bb_launch_add_constraint(b, count, nparents, rows_max, cols_max, side, any_inplace);
     std::vector<int> kept_pivots;
     if (keep) {  // tableaux[0]: what AddConstraint hands to DoDualSimplex (:1105,:1172)
         keep->tabs.assign(count, {});
@@ -751,7 +772,8 @@ int lpr_bb_run(lpr_bb* b, const lpr_bb_opts* opts, double* x, lpr_bb_result* res
         int32_t kinds[2] = {0, 1};
         int32_t child[2] = {-1, -1}, cst[2] = {0, 0}, cpiv[2] = {0, 0};
         std::vector<int32_t> tr, off;
-        rc = bb_expand(b, 2, parents, vars, bounds, kinds, child, cst, cpiv, &tr, &off);
+        rc = bb_expand(b, 2, parents, vars, bounds, kinds, child, cst, cpiv, &tr, &off, nullptr,
+                       /*consume=*/true);
         if (rc != LPR_OK_OPTIMAL) {
             if (rc == LPR_BB_NODE_CAP) { status = rc; break; }
             return rc;
@@ -952,7 +974,8 @@ int lpr_bb_solve_level_sync(lpr_bb* b, lpr_comm* comm, const lpr_bb_sync_opts* o
             cpiv.assign(cnt, 0);
             const double t_e = bb_now();
             local_rc = bb_expand(b, cnt, parents.data(), var.data(), bound.data(), kind.data(),
-                                 child.data(), cst.data(), cpiv.data(), nullptr, nullptr);
+                                 child.data(), cst.data(), cpiv.data(), nullptr, nullptr, nullptr,
+                                 /*consume=*/true);
             b->prof.expand += bb_now() - t_e;
             for (int q = 0; q < cnt && local_rc == LPR_OK_OPTIMAL; ++q) {
                 if (count_here) pivots += cpiv[q];

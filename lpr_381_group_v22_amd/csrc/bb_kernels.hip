@@ -130,19 +130,31 @@ __device__ __forceinline__ int block_min_int(int v, int* lds) {
 // :747).
 constexpr int kBBRowsPerThread = 8;  // rows a thread of the element-wise passes walks
 
+// Per node, one byte per row behind its scores (row rows_cap + 1 of its buffer: 1 + nvars doubles
+// are used, and 8 (ld - 1 - nvars) >= rows_cap bytes are left): 1 = k_bb_finish stored a -0.0 in
+// that row (Math.Round of a tiny negative value).  The children of the node start from its rows
+// with -0 made +0 (:307-313); a child that takes the buffer over in place only has to visit the
+// flagged rows for that.
+__device__ __forceinline__ uint8_t* bb_negz(double* T, int ld, int rows_cap, int nvars) {
+    return reinterpret_cast<uint8_t*>(T + (size_t)(rows_cap + 1) * ld + 1 + nvars);
+}
+
 __global__ __launch_bounds__(256) void k_bb_child_init(const BBSlot* __restrict__ slots, int ld,
                                                        uint8_t* __restrict__ touched_all,
-                                                       int rows_cap16) {
+                                                       int rows_cap16, int rows_cap, int nvars) {
     const BBSlot& s = slots[blockIdx.z];
+    if (s.inplace) return;  // (k_bb_child_inplace)
     const int Rc = s.rows, Cc = s.cols;
     const int R = Rc - 1, C = Cc - 1;  // parent shape
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int i0 = blockIdx.y * kBBRowsPerThread;
     // every row starts as a rounded copy of the parent's: untouched -- except the appended row,
-    // which k_bb_eliminate rewrites (:756-796)
-    if (blockIdx.x == 0 && threadIdx.x < kBBRowsPerThread && i0 + (int)threadIdx.x < rows_cap16)
+    // which k_bb_eliminate rewrites (:756-796); and no row holds a -0 yet (bb_negz)
+    if (blockIdx.x == 0 && threadIdx.x < kBBRowsPerThread && i0 + (int)threadIdx.x < rows_cap16) {
         touched_all[(size_t)blockIdx.z * rows_cap16 + i0 + threadIdx.x] =
             (i0 + (int)threadIdx.x == Rc - 1) ? 1 : 0;
+        if (i0 + (int)threadIdx.x < rows_cap) bb_negz(s.cur, ld, rows_cap, nvars)[i0 + threadIdx.x] = 0;
+    }
     if (j >= ld) return;
     const double* __restrict__ P = s.parent;
 #pragma unroll
@@ -165,6 +177,69 @@ __global__ __launch_bounds__(256) void k_bb_child_init(const BBSlot* __restrict_
         }
         s.cur[(size_t)i * ld + j] = v;
     }
+}
+
+// grid (nslots).  The second child of a parent takes the parent's buffer over (slot.inplace): the
+// parent's rows are what k_bb_child_init would write -- they have been through RoundNumber (the
+// parent is not `big`), so rounding them again changes nothing -- except that the right-hand side
+// moves one column to the right, the inserted column is 0 (:716-719) and a -0.0 becomes +0.0
+// (:307-313): only in the rows k_bb_finish flagged.  Then the branching row (:721-744).  Runs
+// AFTER k_bb_child_init of the batch (the sibling copies the parent's rows first).
+__global__ __launch_bounds__(256) void k_bb_child_inplace(const BBSlot* __restrict__ slots, int ld,
+                                                          uint8_t* __restrict__ touched_all,
+                                                          int rows_cap16, int rows_cap, int nvars) {
+    const BBSlot& s = slots[blockIdx.x];
+    if (!s.inplace) return;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int Rc = s.rows, Cc = s.cols;
+    const int R = Rc - 1, C = Cc - 1;  // parent shape
+    double* __restrict__ T = s.cur;
+    uint8_t* __restrict__ negz = bb_negz(T, ld, rows_cap, nvars);
+    uint8_t* __restrict__ touched = touched_all + (size_t)blockIdx.x * rows_cap16;
+    __shared__ int s_nz, s_rows[256];
+    if (tid == 0) s_nz = 0;
+    __syncthreads();
+    for (int i = tid; i < R; i += nt) {
+        double rhs = T[(size_t)i * ld + (C - 1)];
+        if (rhs == 0.0) rhs = 0.0;
+        T[(size_t)i * ld + C] = rhs;
+        T[(size_t)i * ld + (C - 1)] = 0.0;
+        touched[i] = 0;
+        if (negz[i]) {  // (rarely any: the flagged rows are listed, 256 at a time at most)
+            const int pos = atomicAdd(&s_nz, 1);
+            if (pos < 256) s_rows[pos] = i;
+        }
+    }
+    __syncthreads();
+    const int nz = s_nz;
+    if (nz <= 256) {
+        for (int q = 0; q < nz; ++q) {
+            const int i = s_rows[q];
+            for (int j = tid; j < C - 1; j += nt) {
+                const double v = T[(size_t)i * ld + j];
+                if (v == 0.0) T[(size_t)i * ld + j] = 0.0;
+            }
+        }
+    } else {  // (more than the list holds: every flagged row, one after the other)
+        for (int i = 0; i < R; ++i) {
+            if (!negz[i]) continue;  // (uniform: every thread reads the same byte)
+            for (int j = tid; j < C - 1; j += nt) {
+                const double v = T[(size_t)i * ld + j];
+                if (v == 0.0) T[(size_t)i * ld + j] = 0.0;
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < rows_cap; i += nt) negz[i] = 0;
+    for (int j = tid; j < ld; j += nt) {
+        double v = 0.0;
+        if (j == s.var) v = 1.0;                        // RoundNumber(1) twice is 1
+        if (j == C) v = dn_round4_twice(s.bound);       // :732
+        if (j == C - 1) v = s.reverse ? -1.0 : 1.0;     // slackPosition :734-742
+        T[(size_t)R * ld + j] = v;
+    }
+    if (tid == 0) touched[R] = 1;
+    for (int i = R + 1 + tid; i < rows_cap16; i += nt) touched[i] = 0;
 }
 
 // grid (ceil(C/64), nslots).  One lane per OLD column k: rounded values summed in row order
@@ -698,6 +773,7 @@ __global__ __launch_bounds__(64) void k_bb_finish(BBSlot* __restrict__ slots, in
     const int R = s.rows, C = s.cols;
     if (k >= C) return;
     double* __restrict__ T = s.cur;
+    uint8_t* __restrict__ negz = bb_negz(T, ld, rows_cap, nvars);
     double sum = 0.0;
     int key = R, frow = -1;
     bool big = false;
@@ -723,6 +799,7 @@ __global__ __launch_bounds__(64) void k_bb_finish(BBSlot* __restrict__ slots, in
                 // (most entries are zeros or come from rows no pivot touched since child_init
                 // rounded them: only a value whose bits change is written back)
                 if (__double_as_longlong(v) != __double_as_longlong(x[d])) T[(size_t)i * ld + k] = v;
+                if (__double_as_longlong(v) == (long long)0x8000000000000000ull) negz[i] = 1;
                 if (i == 0) v0 = v;
                 // working = Round(base) :702, Identify :655, :812-821 round v again: below 1e11
                 // that gives v back (above, slot.big is set and none of this is used)
@@ -831,12 +908,15 @@ void bb_launch_gather_info(lpr_bb* b, int count) {
 }
 
 void bb_launch_add_constraint(lpr_bb* b, int nslots, int nparents, int rows_max, int cols_max,
-                              bool side) {
+                              bool side, bool inplace) {
     hipStream_t st = b->eng->stream;
     const dim3 egrid((b->ld + 255) / 256, (rows_max + kBBRowsPerThread - 1) / kBBRowsPerThread,
                      nslots);
     hipLaunchKernelGGL(k_bb_child_init, egrid, dim3(256), 0, st, b->d_slots, b->ld, b->touched,
-                       align_up(b->rows_cap, 16));
+                       align_up(b->rows_cap, 16), b->rows_cap, b->nvars);
+    if (inplace)
+        hipLaunchKernelGGL(k_bb_child_inplace, dim3(nslots), dim3(256), 0, st, b->d_slots, b->ld,
+                           b->touched, align_up(b->rows_cap, 16), b->rows_cap, b->nvars);
     if (!side)  // (otherwise every parent carries its scan in its own buffer: k_bb_finish)
         hipLaunchKernelGGL(k_bb_basic_scan, dim3((cols_max + 63) / 64, nparents), dim3(64), 0, st,
                            b->d_slots, b->ld, b->bflag, b->bkey);
