@@ -225,6 +225,48 @@ def test_level_sync_bound_outside_int_range(engine, oracle):
             assert bits(nat["z"]) == bits(py["z"]) == bits(orc["z"]), levels
 
 
+def test_inplace_second_child_starts_from_a_parent_that_holds_negative_zeros(engine, oracle):
+    """The tree drivers let the second child of a parent take the parent's buffer over
+    (k_bb_child_inplace): the stored parent keeps the -0.0 that Math.Round(-0.00001, 4) leaves
+    (:1124 / :1187), its children start from +0.0 (:307-313), so the rows k_bb_finish flagged are
+    cleaned in place.  An instance on which 40 expanded parents hold a -0.0 (checked on the
+    oracle's own nodes): the native level-synchronous search and the reference's DFS against the
+    oracle."""
+    from oracle_evaluator import OracleEvaluator
+    from lpr_381_group_v22_amd import (BranchBoundTree, solve_level_sync_native,
+                                       solve_level_synchronous)
+    obj, cons = bb_cases.fractional_program(9, 4, 1)
+    st, T, n = bb_cases.primal_final_tableau(oracle, obj, cons)
+    assert st == 0
+    ev = OracleEvaluator(oracle, T, n)
+    seen = {"negz": 0}
+    inner = ev.expand
+
+    def expand(parents, var, bound, kind):
+        for p in set(int(x) for x in parents):
+            if p != 0 and np.any((ev.nodes[p] == 0.0) & np.signbit(ev.nodes[p])):
+                seen["negz"] += 1
+        return inner(parents, var, bound, kind)
+
+    ev.expand = expand
+    orc = solve_level_synchronous(ev, n, max_levels=6)
+    assert seen["negz"] >= 10
+    tree = BranchBoundTree.from_array(engine, T, n, max_depth=16)
+    nat = solve_level_sync_native(tree, max_levels=6)
+    tree.destroy()
+    for key in ("processed", "pivots", "levels", "found", "status"):
+        assert nat[key] == orc[key], key
+    assert bits(nat["z"]) == bits(orc["z"])
+    if orc["found"]:
+        assert [bits(v) for v in nat["x"]] == [bits(v) for v in orc["x"]]
+    # and the DFS driver (two children per expansion: the second one in place) node by node
+    ref = oracle.bb_solve(T, n, node_cap=60)
+    got = gpu_run(engine, T, n, 60)
+    assert got["processed"] == ref["processed"] and got["records"] == ref["records"]
+    assert got["pop_order"] == ref["pop_order"] and got["trace"] == ref["trace"]
+    assert bits(got["z"]) == bits(ref["z"])
+
+
 def test_rccl_communicator_of_one_rank(engine, oracle):
     """lpr_comm_init -> ncclCommInitRank inside the library (world size 1: the pool gives one GPU);
     the levels' all-reduce(MAX) and the final all-gather really go through RCCL: one all-reduce per
